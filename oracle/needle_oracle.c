@@ -1,0 +1,1132 @@
+/*
+ * needle_oracle.c -- CPU restatement of the reference's batched vector-search
+ * arithmetic.  TEST INFRASTRUCTURE ONLY: it is the checker the HIP path is
+ * compared against (tests/, the smoke check, the bench's cpu_baseline leg).
+ * Nothing in the shipped library links, loads or calls this file.
+ *
+ * Parity pin: the reference is Rust and cannot be compiled where this was
+ * written, so every function below restates the cited reference lines
+ * operation for operation (same association order, separate multiply and add,
+ * IEEE sqrt/div) and is checked against the reference's own known-answer
+ * tests (tests/test_oracle_reference_kats.py).  Results for which the
+ * reference holds no value-pinning test (top-k membership for n > k, IVF
+ * probe lists, trained codebooks) are pinned by this restatement alone.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (no FMA contraction, no
+ * reassociation: the same roundings as the reference's default x86-64 build,
+ * which has no target-feature flags and therefore takes the scalar paths).
+ *
+ * All citations are relative to the reference repository root.
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+
+#define NDL_API __attribute__((visibility("default")))
+
+/* DistanceFunction discriminants: src/distance.rs:43-73 (declaration order). */
+enum {
+    NDL_COSINE = 0,
+    NDL_COSINE_NORMALIZED = 1,
+    NDL_EUCLIDEAN = 2,
+    NDL_DOT_PRODUCT = 3,
+    NDL_MANHATTAN = 4,
+    NDL_HAMMING = 5,
+    NDL_CHEBYSHEV = 6
+};
+
+/* ------------------------------------------------------------------ */
+/* src/distance.rs scalar kernels                                      */
+/* ------------------------------------------------------------------ */
+
+/* dot_product_scalar, src/distance.rs:284-286: iter().zip().map(x*y).sum().
+ * f32::sum folds from -0.0 (toolchain pinned at 1.85) in index order. */
+NDL_API float ndl_dot(const float *a, const float *b, size_t n) {
+    float s = -0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        float p = a[i] * b[i];
+        s = s + p;
+    }
+    return s;
+}
+
+/* euclidean_squared_scalar, src/distance.rs:249-257. */
+NDL_API float ndl_euclidean_squared(const float *a, const float *b, size_t n) {
+    float s = -0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        float d = a[i] - b[i];
+        float p = d * d;
+        s = s + p;
+    }
+    return s;
+}
+
+/* euclidean_distance, src/distance.rs:203-205. */
+NDL_API float ndl_euclidean(const float *a, const float *b, size_t n) {
+    return sqrtf(ndl_euclidean_squared(a, b, n));
+}
+
+/* cosine_distance, src/distance.rs:153-164: three dot products, both norms
+ * recomputed for every pair, zero norm -> 1.0. */
+NDL_API float ndl_cosine(const float *a, const float *b, size_t n) {
+    float dot = ndl_dot(a, b, n);
+    float na = sqrtf(ndl_dot(a, a, n));
+    float nb = sqrtf(ndl_dot(b, b, n));
+    if (na == 0.0f || nb == 0.0f) return 1.0f;
+    return 1.0f - (dot / (na * nb));
+}
+
+/* cosine_distance_normalized, src/distance.rs:193-196. */
+NDL_API float ndl_cosine_normalized(const float *a, const float *b, size_t n) {
+    return 1.0f - ndl_dot(a, b, n);
+}
+
+/* dot_product_distance, src/distance.rs:264-266. */
+NDL_API float ndl_dot_distance(const float *a, const float *b, size_t n) {
+    return -ndl_dot(a, b, n);
+}
+
+/* manhattan_scalar, src/distance.rs:360-362. */
+NDL_API float ndl_manhattan(const float *a, const float *b, size_t n) {
+    float s = -0.0f;
+    for (size_t i = 0; i < n; ++i) s = s + fabsf(a[i] - b[i]);
+    return s;
+}
+
+/* hamming_distance, src/distance.rs:387-395. */
+NDL_API float ndl_hamming(const float *a, const float *b, size_t n) {
+    size_t c = 0;
+    for (size_t i = 0; i < n; ++i) c += ((a[i] != 0.0f) != (b[i] != 0.0f));
+    return (float)c;
+}
+
+/* chebyshev_distance, src/distance.rs:415-423: fold(0.0, f32::max); f32::max
+ * returns the non-NaN operand. */
+NDL_API float ndl_chebyshev(const float *a, const float *b, size_t n) {
+    float m = 0.0f;
+    for (size_t i = 0; i < n; ++i) m = fmaxf(m, fabsf(a[i] - b[i]));
+    return m;
+}
+
+/* DistanceFunction::compute, src/distance.rs:93-103. */
+NDL_API float ndl_compute(int metric, const float *a, const float *b, size_t n) {
+    switch (metric) {
+    case NDL_COSINE: return ndl_cosine(a, b, n);
+    case NDL_COSINE_NORMALIZED: return ndl_cosine_normalized(a, b, n);
+    case NDL_EUCLIDEAN: return ndl_euclidean(a, b, n);
+    case NDL_DOT_PRODUCT: return ndl_dot_distance(a, b, n);
+    case NDL_MANHATTAN: return ndl_manhattan(a, b, n);
+    case NDL_HAMMING: return ndl_hamming(a, b, n);
+    case NDL_CHEBYSHEV: return ndl_chebyshev(a, b, n);
+    default: return NAN;
+    }
+}
+
+/* normalize, src/distance.rs:426-434 + 464-469: reciprocal then multiply. */
+NDL_API void ndl_normalize(float *v, size_t n) {
+    float norm = sqrtf(ndl_dot(v, v, n));
+    if (norm > 0.0f) {
+        float inv = 1.0f / norm;
+        for (size_t i = 0; i < n; ++i) v[i] = v[i] * inv;
+    }
+}
+
+/* FromStr for DistanceFunction, src/distance.rs:132-145 (case-insensitive).
+ * Returns the discriminant or -1. */
+NDL_API int ndl_metric_from_str(const char *s) {
+    static const struct { const char *name; int m; } tab[] = {
+        {"cosine", NDL_COSINE},
+        {"cosine_normalized", NDL_COSINE_NORMALIZED},
+        {"cosinenormalized", NDL_COSINE_NORMALIZED},
+        {"euclidean", NDL_EUCLIDEAN}, {"l2", NDL_EUCLIDEAN},
+        {"dot", NDL_DOT_PRODUCT}, {"dotproduct", NDL_DOT_PRODUCT},
+        {"dot_product", NDL_DOT_PRODUCT}, {"inner_product", NDL_DOT_PRODUCT},
+        {"manhattan", NDL_MANHATTAN}, {"l1", NDL_MANHATTAN},
+        {"hamming", NDL_HAMMING},
+        {"chebyshev", NDL_CHEBYSHEV}, {"linf", NDL_CHEBYSHEV},
+        {"l_inf", NDL_CHEBYSHEV}, {"l_infinity", NDL_CHEBYSHEV},
+    };
+    for (size_t i = 0; i < sizeof(tab) / sizeof(tab[0]); ++i)
+        if (strcasecmp(s, tab[i].name) == 0) return tab[i].m;
+    return -1;
+}
+
+/* validate_vector, src/collection/validation.rs:8-24: 0 ok, 1 NaN, 2 Inf;
+ * *bad_index receives the offending position. */
+NDL_API int ndl_validate_vector(const float *v, size_t n, size_t *bad_index) {
+    for (size_t i = 0; i < n; ++i) {
+        if (isnan(v[i])) { if (bad_index) *bad_index = i; return 1; }
+        if (isinf(v[i])) { if (bad_index) *bad_index = i; return 2; }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Ordering: OrderedFloat (ordered-float 4.6.0): NaN greatest, -0 == +0 */
+/* ------------------------------------------------------------------ */
+static inline int of_cmp(float a, float b) {
+    int an = isnan(a), bn = isnan(b);
+    if (an || bn) return an - bn; /* NaN == NaN, NaN > everything else */
+    return (a > b) - (a < b);
+}
+
+typedef struct { float d; uint64_t id; } ndl_hit;
+
+/* (distance, id) ascending: the order a stable sort_by_key(OrderedFloat(d))
+ * over an index-ordered vector produces (src/recall_benchmark.rs:199). */
+static int hit_cmp(const void *pa, const void *pb) {
+    const ndl_hit *a = (const ndl_hit *)pa, *b = (const ndl_hit *)pb;
+    int c = of_cmp(a->d, b->d);
+    if (c) return c;
+    return (a->id > b->id) - (a->id < b->id);
+}
+
+/* Bounded max-heap on (d,id): keeps the k smallest hits seen so far. */
+typedef struct { ndl_hit *h; size_t n, cap; } ndl_heap;
+static void heap_sift_down(ndl_heap *hp, size_t i) {
+    for (;;) {
+        size_t l = 2 * i + 1, r = l + 1, m = i;
+        if (l < hp->n && hit_cmp(&hp->h[l], &hp->h[m]) > 0) m = l;
+        if (r < hp->n && hit_cmp(&hp->h[r], &hp->h[m]) > 0) m = r;
+        if (m == i) return;
+        ndl_hit t = hp->h[i]; hp->h[i] = hp->h[m]; hp->h[m] = t; i = m;
+    }
+}
+static void heap_offer(ndl_heap *hp, ndl_hit x) {
+    if (hp->cap == 0) return;
+    if (hp->n < hp->cap) {
+        size_t i = hp->n++;
+        hp->h[i] = x;
+        while (i > 0) {
+            size_t p = (i - 1) / 2;
+            if (hit_cmp(&hp->h[i], &hp->h[p]) <= 0) break;
+            ndl_hit t = hp->h[i]; hp->h[i] = hp->h[p]; hp->h[p] = t; i = p;
+        }
+    } else if (hit_cmp(&x, &hp->h[0]) < 0) {
+        hp->h[0] = x;
+        heap_sift_down(hp, 0);
+    }
+}
+
+/* Min-heap used only by the forensic "evict nearest" mode below. */
+static void minheap_sift_down(ndl_heap *hp, size_t i) {
+    for (;;) {
+        size_t l = 2 * i + 1, r = l + 1, m = i;
+        if (l < hp->n && hit_cmp(&hp->h[l], &hp->h[m]) < 0) m = l;
+        if (r < hp->n && hit_cmp(&hp->h[r], &hp->h[m]) < 0) m = r;
+        if (m == i) return;
+        ndl_hit t = hp->h[i]; hp->h[i] = hp->h[m]; hp->h[m] = t; i = m;
+    }
+}
+static void minheap_push(ndl_heap *hp, ndl_hit x) {
+    size_t i = hp->n++;
+    hp->h[i] = x;
+    while (i > 0) {
+        size_t p = (i - 1) / 2;
+        if (hit_cmp(&hp->h[i], &hp->h[p]) >= 0) break;
+        ndl_hit t = hp->h[i]; hp->h[i] = hp->h[p]; hp->h[p] = t; i = p;
+    }
+}
+static void minheap_pop(ndl_heap *hp) {
+    hp->h[0] = hp->h[--hp->n];
+    if (hp->n) minheap_sift_down(hp, 0);
+}
+
+static inline int bit_get(const uint32_t *mask, uint64_t i) {
+    return (mask[i >> 5] >> (i & 31)) & 1u;
+}
+
+/* ------------------------------------------------------------------ */
+/* Exact flat search                                                   */
+/* ------------------------------------------------------------------ */
+
+/*
+ * One query of the exact flat scan.
+ *   semantics: compute_ground_truth, src/recall_benchmark.rs:183-207 (all N
+ *   distances, stable sort by distance, truncate k  ==  k smallest by
+ *   (distance, index)), with the skip rules of Collection::brute_force_search,
+ *   src/collection/search_methods.rs:203-223: a row is scanned only when its
+ *   bit in `valid` (deleted / expired rows cleared) and in `filter` (rows
+ *   failing the metadata pre-filter cleared) is set; either mask may be NULL.
+ *   k is clamped to the number of scanned rows (clamp_k, validation.rs:39-41,
+ *   generalised to the masked count).
+ * evict_nearest != 0 reproduces, for forensics only, the heap of
+ *   search_methods.rs:229-234 whose pop() discards the SMALLEST distance once
+ *   more than k rows were pushed.
+ * Returns the number of hits written (ascending by (distance, id)).
+ */
+static size_t flat_search_one(const float *query, const float *base, uint64_t n,
+                              size_t dim, size_t k, int metric,
+                              const uint32_t *valid, const uint32_t *filter,
+                              int evict_nearest, uint64_t *out_ids,
+                              float *out_dists) {
+    if (k == 0) return 0;
+    ndl_heap hp;
+    hp.n = 0;
+    hp.cap = k;
+    hp.h = (ndl_hit *)malloc(sizeof(ndl_hit) * (k + 1));
+    for (uint64_t i = 0; i < n; ++i) {
+        if (valid && !bit_get(valid, i)) continue;
+        if (filter && !bit_get(filter, i)) continue;
+        ndl_hit x;
+        x.d = ndl_compute(metric, query, base + i * dim, dim);
+        x.id = i;
+        if (!evict_nearest) {
+            heap_offer(&hp, x);
+        } else {
+            minheap_push(&hp, x);
+            if (hp.n > k) minheap_pop(&hp);
+        }
+    }
+    size_t m = hp.n;
+    qsort(hp.h, m, sizeof(ndl_hit), hit_cmp);
+    for (size_t j = 0; j < m; ++j) { out_ids[j] = hp.h[j].id; out_dists[j] = hp.h[j].d; }
+    free(hp.h);
+    return m;
+}
+
+typedef struct {
+    const float *queries, *base;
+    uint64_t n; size_t nq, dim, k; int metric;
+    const uint32_t *valid, *filter; int evict_nearest;
+    uint64_t *out_ids; float *out_dists; uint32_t *out_counts;
+    size_t next; pthread_mutex_t mu;
+} flat_job;
+
+static void *flat_worker(void *arg) {
+    flat_job *jb = (flat_job *)arg;
+    for (;;) {
+        pthread_mutex_lock(&jb->mu);
+        size_t q = jb->next++;
+        pthread_mutex_unlock(&jb->mu);
+        if (q >= jb->nq) break;
+        size_t m = flat_search_one(jb->queries + q * jb->dim, jb->base, jb->n, jb->dim,
+                                   jb->k, jb->metric, jb->valid, jb->filter,
+                                   jb->evict_nearest, jb->out_ids + q * jb->k,
+                                   jb->out_dists + q * jb->k);
+        jb->out_counts[q] = (uint32_t)m;
+    }
+    return NULL;
+}
+
+/*
+ * Batch exact flat search: one task per query over `threads` host threads,
+ * the structure of queries.par_iter() in src/collection/batch.rs:46-52.
+ * Outputs are [nq][k] row-major, rows padded beyond out_counts[q].
+ */
+NDL_API void ndl_flat_batch_search(const float *queries, size_t nq, const float *base,
+                                   uint64_t n, size_t dim, size_t k, int metric,
+                                   const uint32_t *valid, const uint32_t *filter,
+                                   int evict_nearest, int threads, uint64_t *out_ids,
+                                   float *out_dists, uint32_t *out_counts) {
+    flat_job jb = {queries, base, n, nq, dim, k, metric, valid, filter, evict_nearest,
+                   out_ids, out_dists, out_counts, 0, PTHREAD_MUTEX_INITIALIZER};
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > nq) threads = nq ? (int)nq : 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    for (int t = 1; t < threads; ++t) pthread_create(&th[t], NULL, flat_worker, &jb);
+    flat_worker(&jb);
+    for (int t = 1; t < threads; ++t) pthread_join(th[t], NULL);
+    free(th);
+}
+
+/* compute_recall, src/recall_benchmark.rs:210-223, on integer ids. */
+NDL_API double ndl_recall(const uint64_t *ann, size_t n_ann, const uint64_t *gt,
+                          size_t n_gt, size_t k) {
+    size_t g = n_gt < k ? n_gt : k, a = n_ann < k ? n_ann : k, found = 0, uniq = 0;
+    for (size_t i = 0; i < g; ++i) { /* HashSet: count distinct ground-truth ids */
+        int dup = 0;
+        for (size_t j = 0; j < i; ++j) if (gt[j] == gt[i]) { dup = 1; break; }
+        uniq += !dup;
+    }
+    for (size_t i = 0; i < a; ++i)
+        for (size_t j = 0; j < g; ++j) if (ann[i] == gt[j]) { ++found; break; }
+    return uniq == 0 ? 1.0 : (double)found / (double)uniq;
+}
+
+/* percentile, src/recall_benchmark.rs:226-232. */
+NDL_API double ndl_percentile(const double *sorted, size_t n, double p) {
+    if (n == 0) return 0.0;
+    double c = ceil((double)n * p);
+    size_t idx = c < 1.0 ? 0 : (size_t)c - 1;
+    if (idx > n - 1) idx = n - 1;
+    return sorted[idx];
+}
+
+/* gen_vector, src/recall_benchmark.rs:171-180 (wrapping u64 LCG). */
+NDL_API void ndl_gen_vector(uint64_t seed, uint64_t idx, size_t dim, float *out) {
+    uint64_t state = seed * 6364136223846793005ULL + idx;
+    for (size_t i = 0; i < dim; ++i) {
+        state = state * 6364136223846793005ULL + 1442695040888963407ULL;
+        float val = ((float)(state >> 33)) / ((float)UINT32_MAX) * 2.0f - 1.0f;
+        out[i] = val;
+    }
+}
+
+NDL_API void ndl_gen_vectors(uint64_t seed, uint64_t first, uint64_t count, size_t dim,
+                             float *out) {
+    for (uint64_t i = 0; i < count; ++i) ndl_gen_vector(seed, first + i, dim, out + i * dim);
+}
+
+/* ------------------------------------------------------------------ */
+/* GpuAccelerator CPU arm: src/experimental/gpu/{common,mod}.rs         */
+/* ------------------------------------------------------------------ */
+
+/* dot_product_simd, src/experimental/gpu/common.rs:515-534: groups of four,
+ * ((p0+p1)+p2)+p3 added to the running sum, scalar remainder. */
+NDL_API float ndl_dot_chunk4(const float *a, const float *b, size_t n) {
+    size_t chunks = n / 4;
+    float sum = 0.0f;
+    for (size_t i = 0; i < chunks; ++i) {
+        size_t o = i * 4;
+        float p0 = a[o] * b[o], p1 = a[o + 1] * b[o + 1];
+        float p2 = a[o + 2] * b[o + 2], p3 = a[o + 3] * b[o + 3];
+        float g = ((p0 + p1) + p2) + p3;
+        sum = sum + g;
+    }
+    for (size_t i = chunks * 4; i < n; ++i) { float p = a[i] * b[i]; sum = sum + p; }
+    return sum;
+}
+
+/* euclidean_distance_simd, src/experimental/gpu/common.rs:536-555. */
+NDL_API float ndl_euclidean_chunk4(const float *a, const float *b, size_t n) {
+    size_t chunks = n / 4;
+    float sum = 0.0f;
+    for (size_t i = 0; i < chunks; ++i) {
+        size_t o = i * 4;
+        float d0 = a[o] - b[o], d1 = a[o + 1] - b[o + 1];
+        float d2 = a[o + 2] - b[o + 2], d3 = a[o + 3] - b[o + 3];
+        float g = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
+        sum = sum + g;
+    }
+    for (size_t i = chunks * 4; i < n; ++i) { float d = a[i] - b[i]; float p = d * d; sum = sum + p; }
+    return sqrtf(sum);
+}
+
+/* cosine_distance_simd_precomputed, src/experimental/gpu/common.rs:572-581. */
+NDL_API float ndl_cosine_chunk4_precomputed(const float *a, const float *b, size_t n,
+                                            float a_norm) {
+    float dot = ndl_dot_chunk4(a, b, n);
+    float nb = sqrtf(ndl_dot_chunk4(b, b, n));
+    if (a_norm == 0.0f || nb == 0.0f) return 1.0f;
+    return 1.0f - (dot / (a_norm * nb));
+}
+
+/* DistanceType of the operator API (gpu/common.rs): 0 Cosine, 1 Euclidean,
+ * 2 DotProduct.  Distances of fused_search, gpu/mod.rs:717-762 (dot product
+ * negated, zero-norm query -> all 1.0). */
+NDL_API void ndl_accel_distances(const float *query, const float *base, size_t n,
+                                 size_t dim, int dtype, float *out) {
+    float qn = sqrtf(ndl_dot_chunk4(query, query, dim));
+    for (size_t i = 0; i < n; ++i) {
+        const float *v = base + i * dim;
+        if (dtype == 0) out[i] = (qn == 0.0f) ? 1.0f : ndl_cosine_chunk4_precomputed(query, v, dim, qn);
+        else if (dtype == 1) out[i] = ndl_euclidean_chunk4(query, v, dim);
+        else out[i] = -ndl_dot_chunk4(query, v, dim);
+    }
+}
+
+/* batch_{cosine,euclidean}_distance / batch_dot_product, gpu/mod.rs:308-448:
+ * like ndl_accel_distances but the dot-product variant is NOT negated. */
+NDL_API void ndl_accel_batch_distance(const float *query, const float *base, size_t n,
+                                      size_t dim, int dtype, float *out) {
+    ndl_accel_distances(query, base, n, dim, dtype, out);
+    if (dtype == 2) for (size_t i = 0; i < n; ++i) out[i] = -out[i];
+}
+
+/* Top-k of a score vector: the k smallest by (score, index), ascending.
+ * Covers batch_top_k (gpu/mod.rs:534-549: stable sort + take k) and
+ * partial_sort_top_k (gpu/common.rs:584-626: max-heap of k with strict '<'
+ * replacement, i.e. earliest index wins ties; its final order among equal
+ * scores is heap-internal and unspecified -- index order is used here).
+ * partial_cmp(..).unwrap_or(Equal) makes NaN compare equal to everything in
+ * the reference; scores are assumed NaN-free here (NaN sorts last). */
+NDL_API size_t ndl_top_k(const float *scores, size_t n, size_t k, uint64_t *out_idx,
+                         float *out_scores) {
+    if (k > n) k = n;
+    if (k == 0) return 0;
+    ndl_heap hp; hp.n = 0; hp.cap = k;
+    hp.h = (ndl_hit *)malloc(sizeof(ndl_hit) * k);
+    for (size_t i = 0; i < n; ++i) { ndl_hit x = {scores[i], i}; heap_offer(&hp, x); }
+    qsort(hp.h, hp.n, sizeof(ndl_hit), hit_cmp);
+    for (size_t j = 0; j < hp.n; ++j) { out_idx[j] = hp.h[j].id; out_scores[j] = hp.h[j].d; }
+    size_t m = hp.n;
+    free(hp.h);
+    return m;
+}
+
+/* fused_search, gpu/mod.rs:706-787: distances then top-k (all rows when
+ * k >= n). */
+NDL_API size_t ndl_accel_fused_search(const float *query, const float *base, size_t n,
+                                      size_t dim, size_t k, int dtype, uint64_t *out_idx,
+                                      float *out_dist) {
+    float *d = (float *)malloc(sizeof(float) * (n ? n : 1));
+    ndl_accel_distances(query, base, n, dim, dtype, d);
+    size_t m = ndl_top_k(d, n, k, out_idx, out_dist);
+    free(d);
+    return m;
+}
+
+typedef struct {
+    const float *queries, *base; size_t nq, n, dim, k; int dtype;
+    uint64_t *out_idx; float *out_dist; uint32_t *out_counts;
+    size_t next; pthread_mutex_t mu;
+} accel_job;
+static void *accel_worker(void *arg) {
+    accel_job *jb = (accel_job *)arg;
+    for (;;) {
+        pthread_mutex_lock(&jb->mu);
+        size_t q = jb->next++;
+        pthread_mutex_unlock(&jb->mu);
+        if (q >= jb->nq) break;
+        jb->out_counts[q] = (uint32_t)ndl_accel_fused_search(
+            jb->queries + q * jb->dim, jb->base, jb->n, jb->dim, jb->k, jb->dtype,
+            jb->out_idx + q * jb->k, jb->out_dist + q * jb->k);
+    }
+    return NULL;
+}
+/* batch_fused_search, gpu/mod.rs:790-823 (queries.par_iter()). */
+NDL_API void ndl_accel_batch_fused_search(const float *queries, size_t nq, const float *base,
+                                          size_t n, size_t dim, size_t k, int dtype,
+                                          int threads, uint64_t *out_idx, float *out_dist,
+                                          uint32_t *out_counts) {
+    accel_job jb = {queries, base, nq, n, dim, k, dtype, out_idx, out_dist, out_counts, 0,
+                    PTHREAD_MUTEX_INITIALIZER};
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > nq) threads = nq ? (int)nq : 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    for (int t = 1; t < threads; ++t) pthread_create(&th[t], NULL, accel_worker, &jb);
+    accel_worker(&jb);
+    for (int t = 1; t < threads; ++t) pthread_join(th[t], NULL);
+    free(th);
+}
+
+/* streaming_batch_search, gpu/mod.rs:855-903: per-chunk fused_search, global
+ * index = chunk_start + local, concat, sort by distance, truncate k. */
+NDL_API size_t ndl_accel_streaming_search(const float *query, const float *base, size_t n,
+                                          size_t dim, size_t k, int dtype, size_t chunk,
+                                          uint64_t *out_idx, float *out_dist) {
+    if (n == 0 || chunk == 0) return 0;
+    size_t nchunks = (n + chunk - 1) / chunk, total = 0;
+    ndl_hit *all = (ndl_hit *)malloc(sizeof(ndl_hit) * (nchunks * (k ? k : 1)));
+    uint64_t *ti = (uint64_t *)malloc(sizeof(uint64_t) * (k ? k : 1));
+    float *td = (float *)malloc(sizeof(float) * (k ? k : 1));
+    for (size_t s = 0; s < n; s += chunk) {
+        size_t e = s + chunk < n ? s + chunk : n;
+        size_t m = ndl_accel_fused_search(query, base + s * dim, e - s, dim, k, dtype, ti, td);
+        for (size_t j = 0; j < m; ++j) { all[total].d = td[j]; all[total].id = s + ti[j]; ++total; }
+    }
+    qsort(all, total, sizeof(ndl_hit), hit_cmp);
+    size_t m = total < k ? total : k;
+    for (size_t j = 0; j < m; ++j) { out_idx[j] = all[j].id; out_dist[j] = all[j].d; }
+    free(all); free(ti); free(td);
+    return m;
+}
+
+/* kmeans_assign, gpu/mod.rs:660-703: argmin of euclidean_distance_simd,
+ * min_by keeps the FIRST minimum. */
+NDL_API void ndl_accel_kmeans_assign(const float *vectors, size_t n, const float *centroids,
+                                     size_t c, size_t dim, uint64_t *out) {
+    for (size_t i = 0; i < n; ++i) {
+        size_t best = 0; float bd = 0.0f;
+        for (size_t j = 0; j < c; ++j) {
+            float d = ndl_euclidean_chunk4(vectors + i * dim, centroids + j * dim, dim);
+            if (j == 0 || d < bd) { bd = d; best = j; }
+        }
+        out[i] = best;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* Shard merge: src/persistence/shard.rs:622-643                        */
+/* ------------------------------------------------------------------ */
+/* Concatenate, stable-sort by distance, drop repeated ids, take k.  Inputs
+ * are `lists` runs of `per` (dist,id) pairs with counts[l] valid entries.
+ * Ties between shards are resolved by (distance, id) -- for row-sharded data
+ * with globally unique ids this equals the reference's stable order whenever
+ * shards are concatenated in id order. */
+NDL_API size_t ndl_merge_topk(const float *dists, const uint64_t *ids,
+                              const uint32_t *counts, size_t lists, size_t per, size_t k,
+                              uint64_t *out_ids, float *out_dists) {
+    size_t total = 0;
+    for (size_t l = 0; l < lists; ++l) total += counts[l];
+    ndl_hit *all = (ndl_hit *)malloc(sizeof(ndl_hit) * (total ? total : 1));
+    size_t t = 0;
+    for (size_t l = 0; l < lists; ++l)
+        for (size_t j = 0; j < counts[l]; ++j) { all[t].d = dists[l * per + j]; all[t].id = ids[l * per + j]; ++t; }
+    qsort(all, total, sizeof(ndl_hit), hit_cmp);
+    size_t m = 0;
+    for (size_t i = 0; i < total && m < k; ++i) {
+        int dup = 0;
+        for (size_t j = 0; j < m; ++j) if (out_ids[j] == all[i].id) { dup = 1; break; }
+        if (dup) continue;
+        out_ids[m] = all[i].id; out_dists[m] = all[i].d; ++m;
+    }
+    free(all);
+    return m;
+}
+
+/* ------------------------------------------------------------------ */
+/* Deterministic RNG for training (the reference draws from thread_rng, */
+/* which is unseeded: trained centroids/codebooks are unpinned there).  */
+/* ------------------------------------------------------------------ */
+static inline uint64_t splitmix64(uint64_t *s) {
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static inline float rng_unit(uint64_t *s) { /* [0,1) with 24 bits */
+    return (float)(splitmix64(s) >> 40) * (1.0f / 16777216.0f);
+}
+
+/* ------------------------------------------------------------------ */
+/* IVF: src/indexing/ivf.rs                                             */
+/* ------------------------------------------------------------------ */
+
+/* find_nearest_centroid, ivf.rs:453-459: min_by_key(OrderedFloat(euclidean))
+ * -> first minimum. */
+NDL_API uint32_t ndl_ivf_nearest_centroid(const float *v, const float *centroids,
+                                          size_t nlist, size_t dim) {
+    size_t best = 0; float bd = 0.0f;
+    for (size_t j = 0; j < nlist; ++j) {
+        float d = ndl_euclidean(v, centroids + j * dim, dim);
+        if (j == 0 || of_cmp(d, bd) < 0) { bd = d; best = j; }
+    }
+    return (uint32_t)best;
+}
+
+typedef struct {
+    const float *base, *centroids; size_t n, nlist, dim; uint32_t *out;
+    size_t next; pthread_mutex_t mu;
+} assign_job;
+static void *assign_worker(void *arg) {
+    assign_job *jb = (assign_job *)arg;
+    for (;;) {
+        pthread_mutex_lock(&jb->mu);
+        size_t s = jb->next; jb->next += 256;
+        pthread_mutex_unlock(&jb->mu);
+        if (s >= jb->n) break;
+        size_t e = s + 256 < jb->n ? s + 256 : jb->n;
+        for (size_t i = s; i < e; ++i)
+            jb->out[i] = ndl_ivf_nearest_centroid(jb->base + i * jb->dim, jb->centroids, jb->nlist, jb->dim);
+    }
+    return NULL;
+}
+/* Assignment of every row (the insert() loop of ivf.rs:462-498). */
+NDL_API void ndl_ivf_assign(const float *base, size_t n, const float *centroids,
+                            size_t nlist, size_t dim, int threads, uint32_t *out) {
+    assign_job jb = {base, centroids, n, nlist, dim, out, 0, PTHREAD_MUTEX_INITIALIZER};
+    if (threads < 1) threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    for (int t = 1; t < threads; ++t) pthread_create(&th[t], NULL, assign_worker, &jb);
+    assign_worker(&jb);
+    for (int t = 1; t < threads; ++t) pthread_join(th[t], NULL);
+    free(th);
+}
+
+/* Coarse step of IvfIndex::search, ivf.rs:521-533: Euclidean distance to
+ * every centroid, stable sort by distance (ties -> lower list id), first
+ * n_probe lists. */
+NDL_API size_t ndl_ivf_probe(const float *query, const float *centroids, size_t nlist,
+                             size_t dim, size_t nprobe, uint32_t *out_lists) {
+    ndl_hit *cd = (ndl_hit *)malloc(sizeof(ndl_hit) * (nlist ? nlist : 1));
+    for (size_t j = 0; j < nlist; ++j) { cd[j].d = ndl_euclidean(query, centroids + j * dim, dim); cd[j].id = j; }
+    qsort(cd, nlist, sizeof(ndl_hit), hit_cmp);
+    size_t m = nprobe < nlist ? nprobe : nlist;
+    for (size_t j = 0; j < m; ++j) out_lists[j] = (uint32_t)cd[j].id;
+    free(cd);
+    return m;
+}
+
+/*
+ * IvfIndex::search, ivf.rs:509-567, over inverted lists in CSR form:
+ * list l owns rows order[offsets[l] .. offsets[l+1]) (insertion order), each
+ * entry an id into `base` (IVF-Flat, Euclidean always: ivf.rs:67,551).
+ * Keeps the k NEAREST by (distance, id); evict_nearest != 0 reproduces the
+ * inverted eviction of ivf.rs:553-556 for forensics.
+ * When pq_codes != NULL the list scan is IVF-PQ (ivf.rs:538-546):
+ * ProductQuantizer::asymmetric_distance on codes[id].
+ */
+struct ndl_pq;
+static float pq_asym(const float *codebooks, size_t m, size_t dsub, const float *query,
+                     const uint8_t *codes);
+NDL_API size_t ndl_ivf_search(const float *query, const float *base, size_t dim,
+                              const float *centroids, size_t nlist,
+                              const uint64_t *offsets, const uint64_t *order,
+                              size_t nprobe, size_t k, int evict_nearest,
+                              const uint8_t *pq_codes, const float *pq_codebooks,
+                              size_t pq_m, uint64_t *out_ids, float *out_dists) {
+    if (k == 0) return 0;
+    uint32_t *probe = (uint32_t *)malloc(sizeof(uint32_t) * (nlist ? nlist : 1));
+    size_t np = ndl_ivf_probe(query, centroids, nlist, dim, nprobe, probe);
+    ndl_heap hp; hp.n = 0; hp.cap = k;
+    hp.h = (ndl_hit *)malloc(sizeof(ndl_hit) * (k + 1));
+    size_t dsub = pq_m ? dim / pq_m : 0;
+    for (size_t p = 0; p < np; ++p) {
+        uint32_t l = probe[p];
+        for (uint64_t e = offsets[l]; e < offsets[l + 1]; ++e) {
+            uint64_t id = order[e];
+            ndl_hit x; x.id = id;
+            if (pq_codes) x.d = pq_asym(pq_codebooks, pq_m, dsub, query, pq_codes + id * pq_m);
+            else x.d = ndl_euclidean(query, base + id * dim, dim);
+            if (!evict_nearest) heap_offer(&hp, x);
+            else { minheap_push(&hp, x); if (hp.n > k) minheap_pop(&hp); }
+        }
+    }
+    size_t m = hp.n;
+    qsort(hp.h, m, sizeof(ndl_hit), hit_cmp);
+    for (size_t j = 0; j < m; ++j) { out_ids[j] = hp.h[j].id; out_dists[j] = hp.h[j].d; }
+    free(hp.h); free(probe);
+    return m;
+}
+
+typedef struct {
+    const float *queries, *base, *centroids; size_t nq, dim, nlist, nprobe, k;
+    const uint64_t *offsets, *order; int evict;
+    const uint8_t *pq_codes; const float *pq_codebooks; size_t pq_m;
+    uint64_t *out_ids; float *out_dists; uint32_t *out_counts;
+    size_t next; pthread_mutex_t mu;
+} ivf_job;
+static void *ivf_worker(void *arg) {
+    ivf_job *jb = (ivf_job *)arg;
+    for (;;) {
+        pthread_mutex_lock(&jb->mu);
+        size_t q = jb->next++;
+        pthread_mutex_unlock(&jb->mu);
+        if (q >= jb->nq) break;
+        jb->out_counts[q] = (uint32_t)ndl_ivf_search(
+            jb->queries + q * jb->dim, jb->base, jb->dim, jb->centroids, jb->nlist, jb->offsets,
+            jb->order, jb->nprobe, jb->k, jb->evict, jb->pq_codes, jb->pq_codebooks, jb->pq_m,
+            jb->out_ids + q * jb->k, jb->out_dists + q * jb->k);
+    }
+    return NULL;
+}
+NDL_API void ndl_ivf_batch_search(const float *queries, size_t nq, const float *base,
+                                  size_t dim, const float *centroids, size_t nlist,
+                                  const uint64_t *offsets, const uint64_t *order,
+                                  size_t nprobe, size_t k, int evict_nearest,
+                                  const uint8_t *pq_codes, const float *pq_codebooks,
+                                  size_t pq_m, int threads, uint64_t *out_ids,
+                                  float *out_dists, uint32_t *out_counts) {
+    ivf_job jb = {queries, base, centroids, nq, dim, nlist, nprobe, k, offsets, order,
+                  evict_nearest, pq_codes, pq_codebooks, pq_m, out_ids, out_dists, out_counts,
+                  0, PTHREAD_MUTEX_INITIALIZER};
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > nq) threads = nq ? (int)nq : 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    for (int t = 1; t < threads; ++t) pthread_create(&th[t], NULL, ivf_worker, &jb);
+    ivf_worker(&jb);
+    for (int t = 1; t < threads; ++t) pthread_join(th[t], NULL);
+    free(th);
+}
+
+/*
+ * IvfIndex::kmeans, ivf.rs:330-395, with k-means++ seeding ivf.rs:398-450,
+ * drawing from a seeded generator instead of thread_rng.  Same control flow:
+ * D^2 weights are the min Euclidean (sqrt'd) distance squared again, the
+ * threshold walk takes the first cumulative sum >= r*total, Lloyd stops when
+ * no assignment changes or the largest centroid shift < tolerance, empty
+ * clusters are re-seeded from a random row.  Returns k = min(nlist, n).
+ */
+NDL_API size_t ndl_ivf_kmeans(const float *vectors, size_t n, size_t dim, size_t nlist,
+                              size_t max_iter, float tol, uint64_t seed, float *centroids) {
+    if (n == 0) return 0;
+    uint64_t rs = seed;
+    size_t k = nlist < n ? nlist : n;
+    size_t nc = 0;
+    memcpy(centroids, vectors + (splitmix64(&rs) % n) * dim, sizeof(float) * dim);
+    nc = 1;
+    float *dist = (float *)malloc(sizeof(float) * n);
+    for (size_t i = 0; i < n; ++i) dist[i] = 3.40282347e+38f;
+    for (size_t c = 1; c < k; ++c) {
+        const float *last = centroids + (nc - 1) * dim;
+        for (size_t i = 0; i < n; ++i) {
+            float d = ndl_euclidean(vectors + i * dim, last, dim);
+            dist[i] = fminf(dist[i], d);
+        }
+        float total = -0.0f;
+        for (size_t i = 0; i < n; ++i) total = total + dist[i] * dist[i];
+        if (total == 0.0f) {
+            size_t *rem = (size_t *)malloc(sizeof(size_t) * n), nr = 0;
+            for (size_t i = 0; i < n; ++i) {
+                int at = 0;
+                for (size_t j = 0; j < nc; ++j)
+                    if (ndl_euclidean(vectors + i * dim, centroids + j * dim, dim) < 1e-10f) { at = 1; break; }
+                if (!at) rem[nr++] = i;
+            }
+            if (nr == 0) { free(rem); break; }
+            size_t idx = rem[splitmix64(&rs) % nr];
+            free(rem);
+            memcpy(centroids + nc * dim, vectors + idx * dim, sizeof(float) * dim);
+            ++nc;
+        } else {
+            float thr = rng_unit(&rs) * total, cum = 0.0f;
+            for (size_t i = 0; i < n; ++i) {
+                cum = cum + dist[i] * dist[i];
+                if (cum >= thr) {
+                    memcpy(centroids + nc * dim, vectors + i * dim, sizeof(float) * dim);
+                    ++nc;
+                    break;
+                }
+            }
+        }
+    }
+    free(dist);
+    k = nc;
+    size_t *assign = (size_t *)calloc(n, sizeof(size_t));
+    float *newc = (float *)malloc(sizeof(float) * k * dim);
+    size_t *counts = (size_t *)malloc(sizeof(size_t) * k);
+    for (size_t it = 0; it < max_iter; ++it) {
+        int changed = 0;
+        for (size_t i = 0; i < n; ++i) {
+            size_t nearest = ndl_ivf_nearest_centroid(vectors + i * dim, centroids, k, dim);
+            if (assign[i] != nearest) { assign[i] = nearest; changed = 1; }
+        }
+        if (!changed) break;
+        for (size_t j = 0; j < k * dim; ++j) newc[j] = 0.0f;
+        memset(counts, 0, sizeof(size_t) * k);
+        for (size_t i = 0; i < n; ++i) {
+            size_t c = assign[i];
+            counts[c] += 1;
+            for (size_t j = 0; j < dim; ++j) newc[c * dim + j] += vectors[i * dim + j];
+        }
+        for (size_t c = 0; c < k; ++c) {
+            if (counts[c] > 0) {
+                float cnt = (float)counts[c];
+                for (size_t j = 0; j < dim; ++j) newc[c * dim + j] /= cnt;
+            } else {
+                memcpy(newc + c * dim, vectors + (splitmix64(&rs) % n) * dim, sizeof(float) * dim);
+            }
+        }
+        float max_shift = 0.0f;
+        for (size_t c = 0; c < k; ++c)
+            max_shift = fmaxf(max_shift, ndl_euclidean(centroids + c * dim, newc + c * dim, dim));
+        memcpy(centroids, newc, sizeof(float) * k * dim);
+        if (max_shift < tol) break;
+    }
+    free(assign); free(newc); free(counts);
+    return k;
+}
+
+/* ------------------------------------------------------------------ */
+/* ScalarQuantizer: src/indexing/quantization.rs:154-286                */
+/* ------------------------------------------------------------------ */
+
+/* train, quantization.rs:154-211.  Returns avg_scale. */
+NDL_API float ndl_sq_train(const float *vectors, size_t n, size_t dim, float *min_vals,
+                           float *max_vals, float *scale) {
+    for (size_t j = 0; j < dim; ++j) { min_vals[j] = 3.40282347e+38f; max_vals[j] = -3.40282347e+38f; }
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = 0; j < dim; ++j) {
+            float v = vectors[i * dim + j];
+            min_vals[j] = fminf(min_vals[j], v);
+            max_vals[j] = fmaxf(max_vals[j], v);
+        }
+    float sum = -0.0f;
+    for (size_t j = 0; j < dim; ++j) {
+        float range = max_vals[j] - min_vals[j];
+        scale[j] = (range > 1e-10f) ? 255.0f / range : 1.0f;
+        sum = sum + scale[j];
+    }
+    return dim ? sum / (float)dim : 1.0f;
+}
+
+/* quantize_into, quantization.rs:232-238: clamp then truncating cast (a NaN
+ * casts to 0). */
+NDL_API void ndl_sq_quantize(const float *v, size_t dim, const float *min_vals,
+                             const float *scale, uint8_t *out) {
+    for (size_t j = 0; j < dim; ++j) {
+        float x = (v[j] - min_vals[j]) * scale[j];
+        if (isnan(x)) { out[j] = 0; continue; }
+        if (x < 0.0f) x = 0.0f;
+        if (x > 255.0f) x = 255.0f;
+        out[j] = (uint8_t)x;
+    }
+}
+
+NDL_API void ndl_sq_quantize_batch(const float *v, size_t n, size_t dim,
+                                   const float *min_vals, const float *scale, uint8_t *out) {
+    for (size_t i = 0; i < n; ++i) ndl_sq_quantize(v + i * dim, dim, min_vals, scale, out + i * dim);
+}
+
+/* dequantize_into, quantization.rs:254-260. */
+NDL_API void ndl_sq_dequantize(const uint8_t *codes, size_t dim, const float *min_vals,
+                               const float *scale, float *out) {
+    for (size_t j = 0; j < dim; ++j) {
+        float x = (float)codes[j] / scale[j];
+        out[j] = x + min_vals[j];
+    }
+}
+
+/* asymmetric_distance, quantization.rs:277-285 (sum starts at +0.0). */
+NDL_API float ndl_sq_asymmetric(const float *query, const uint8_t *codes, size_t dim,
+                                const float *min_vals, const float *scale) {
+    float sum = 0.0f;
+    for (size_t j = 0; j < dim; ++j) {
+        float decoded = ((float)codes[j] / scale[j]) + min_vals[j];
+        float diff = query[j] - decoded;
+        sum += diff * diff;
+    }
+    return sqrtf(sum);
+}
+
+/* distance_squared, quantization.rs:265-274. */
+NDL_API float ndl_sq_distance_squared(const uint8_t *a, const uint8_t *b, size_t dim,
+                                      float avg_scale) {
+    uint32_t sum = 0;
+    for (size_t j = 0; j < dim; ++j) {
+        int32_t diff = (int32_t)a[j] - (int32_t)b[j];
+        sum += (uint32_t)(diff * diff);
+    }
+    return ((float)sum) / (avg_scale * avg_scale);
+}
+
+/* ------------------------------------------------------------------ */
+/* ProductQuantizer: src/indexing/quantization.rs:317-504, 597-722      */
+/* ------------------------------------------------------------------ */
+
+/* euclidean_distance_squared (module-local), quantization.rs:714-722. */
+static float q_l2sq(const float *a, const float *b, size_t n) {
+    float s = -0.0f;
+    for (size_t i = 0; i < n; ++i) { float d = a[i] - b[i]; s = s + d * d; }
+    return s;
+}
+
+/* kmeans, quantization.rs:597-711, seeded.  vectors are [n][dim] contiguous
+ * with row stride `stride`.  Writes min(k,n) centroids, returns that count. */
+static size_t q_kmeans(const float *vectors, size_t n, size_t dim, size_t stride, size_t k,
+                       size_t max_iter, uint64_t *rs, float *centroids) {
+    if (n == 0 || k == 0) return 0;
+    if (k > n) k = n;
+    size_t nc = 0;
+    memcpy(centroids, vectors + (splitmix64(rs) % n) * stride, sizeof(float) * dim);
+    nc = 1;
+    float *dist = (float *)malloc(sizeof(float) * n);
+    while (nc < k) {
+        for (size_t i = 0; i < n; ++i) {
+            float best = 3.40282347e+38f;
+            for (size_t c = 0; c < nc; ++c) best = fminf(best, q_l2sq(vectors + i * stride, centroids + c * dim, dim));
+            dist[i] = best;
+        }
+        float total = -0.0f;
+        for (size_t i = 0; i < n; ++i) total = total + dist[i];
+        if (total <= 0.0f) {
+            size_t *rem = (size_t *)malloc(sizeof(size_t) * n), nr = 0;
+            for (size_t i = 0; i < n; ++i) {
+                int at = 0;
+                for (size_t c = 0; c < nc; ++c)
+                    if (memcmp(vectors + i * stride, centroids + c * dim, sizeof(float) * dim) == 0) { at = 1; break; }
+                if (!at) rem[nr++] = i;
+            }
+            if (nr == 0) { free(rem); break; }
+            size_t idx = rem[splitmix64(rs) % nr];
+            free(rem);
+            memcpy(centroids + nc * dim, vectors + idx * stride, sizeof(float) * dim);
+            ++nc;
+            continue;
+        }
+        for (size_t i = 0; i < n; ++i) dist[i] /= total;
+        float r = rng_unit(rs), cum = 0.0f;
+        int pushed = 0;
+        for (size_t i = 0; i < n; ++i) {
+            cum += dist[i];
+            if (cum >= r) {
+                memcpy(centroids + nc * dim, vectors + i * stride, sizeof(float) * dim);
+                ++nc; pushed = 1;
+                break;
+            }
+        }
+        /* rounding can leave cum < r after the walk: the reference then loops
+         * again with a fresh draw; do the same. */
+        (void)pushed;
+    }
+    free(dist);
+    k = nc;
+    size_t *assign = (size_t *)calloc(n, sizeof(size_t));
+    float *newc = (float *)malloc(sizeof(float) * k * dim);
+    size_t *counts = (size_t *)malloc(sizeof(size_t) * k);
+    for (size_t it = 0; it < max_iter; ++it) {
+        int changed = 0;
+        for (size_t i = 0; i < n; ++i) {
+            size_t bc = 0; float bd = 3.40282347e+38f;
+            for (size_t c = 0; c < k; ++c) {
+                float d = q_l2sq(vectors + i * stride, centroids + c * dim, dim);
+                if (d < bd) { bd = d; bc = c; }
+            }
+            if (assign[i] != bc) { assign[i] = bc; changed = 1; }
+        }
+        if (!changed) break;
+        for (size_t j = 0; j < k * dim; ++j) newc[j] = 0.0f;
+        memset(counts, 0, sizeof(size_t) * k);
+        for (size_t i = 0; i < n; ++i) {
+            size_t c = assign[i];
+            counts[c] += 1;
+            for (size_t j = 0; j < dim; ++j) newc[c * dim + j] += vectors[i * stride + j];
+        }
+        for (size_t c = 0; c < k; ++c) {
+            if (counts[c] > 0) {
+                float cnt = (float)counts[c];
+                for (size_t j = 0; j < dim; ++j) newc[c * dim + j] /= cnt;
+            } else {
+                memcpy(newc + c * dim, vectors + (splitmix64(rs) % n) * stride, sizeof(float) * dim);
+            }
+        }
+        memcpy(centroids, newc, sizeof(float) * k * dim);
+    }
+    free(assign); free(newc); free(counts);
+    return k;
+}
+
+/* ProductQuantizer::train, quantization.rs:330-364: dsub = dim / m, 256
+ * centroids per subspace, 20 Lloyd iterations, on raw sub-vectors.
+ * codebooks is [m][256][dsub]; subspaces with fewer than 256 training rows
+ * leave the tail zero-filled and report the count in ncent[m]. */
+NDL_API void ndl_pq_train(const float *vectors, size_t n, size_t dim, size_t m,
+                          uint64_t seed, float *codebooks, uint32_t *ncent) {
+    size_t dsub = dim / m;
+    uint64_t rs = seed;
+    memset(codebooks, 0, sizeof(float) * m * 256 * dsub);
+    for (size_t s = 0; s < m; ++s) {
+        size_t k = q_kmeans(vectors + s * dsub, n, dsub, dim, 256, 20, &rs, codebooks + s * 256 * dsub);
+        if (ncent) ncent[s] = (uint32_t)k;
+    }
+}
+
+/* encode / find_nearest_centroid, quantization.rs:390-446: strict '<' from
+ * f32::MAX -> first minimum.  ncent may be NULL (256 everywhere). */
+NDL_API void ndl_pq_encode(const float *v, size_t dim, size_t m, const float *codebooks,
+                           const uint32_t *ncent, uint8_t *out) {
+    size_t dsub = dim / m;
+    for (size_t s = 0; s < m; ++s) {
+        size_t k = ncent ? ncent[s] : 256;
+        uint8_t best = 0; float bd = 3.40282347e+38f;
+        for (size_t c = 0; c < k; ++c) {
+            float d = q_l2sq(v + s * dsub, codebooks + (s * 256 + c) * dsub, dsub);
+            if (d < bd) { bd = d; best = (uint8_t)c; }
+        }
+        out[s] = best;
+    }
+}
+
+NDL_API void ndl_pq_encode_batch(const float *v, size_t n, size_t dim, size_t m,
+                                 const float *codebooks, const uint32_t *ncent,
+                                 uint8_t *out) {
+    for (size_t i = 0; i < n; ++i) ndl_pq_encode(v + i * dim, dim, m, codebooks, ncent, out + i * m);
+}
+
+/* decode_into, quantization.rs:414-422. */
+NDL_API void ndl_pq_decode(const uint8_t *codes, size_t dim, size_t m, const float *codebooks,
+                           float *out) {
+    size_t dsub = dim / m;
+    for (size_t s = 0; s < m; ++s)
+        memcpy(out + s * dsub, codebooks + (s * 256 + codes[s]) * dsub, sizeof(float) * dsub);
+}
+
+/* asymmetric_distance, quantization.rs:449-465: ONE accumulator from +0.0
+ * across all subspaces and dimensions, then sqrt. */
+static float pq_asym(const float *codebooks, size_t m, size_t dsub, const float *query,
+                     const uint8_t *codes) {
+    float dist = 0.0f;
+    for (size_t s = 0; s < m; ++s) {
+        const float *c = codebooks + (s * 256 + codes[s]) * dsub;
+        const float *q = query + s * dsub;
+        for (size_t j = 0; j < dsub; ++j) { float diff = q[j] - c[j]; dist += diff * diff; }
+    }
+    return sqrtf(dist);
+}
+NDL_API float ndl_pq_asymmetric(const float *query, const uint8_t *codes, size_t dim, size_t m,
+                                const float *codebooks) {
+    return pq_asym(codebooks, m, dim / m, query, codes);
+}
+
+/* compute_distance_table, quantization.rs:468-494: table[m][256], each entry
+ * a per-subspace sum folded from -0.0. */
+NDL_API void ndl_pq_distance_table(const float *query, size_t dim, size_t m,
+                                   const float *codebooks, float *table) {
+    size_t dsub = dim / m;
+    for (size_t s = 0; s < m; ++s)
+        for (size_t c = 0; c < 256; ++c)
+            table[s * 256 + c] = q_l2sq(query + s * dsub, codebooks + (s * 256 + c) * dsub, dsub);
+}
+
+/* distance_with_table, quantization.rs:497-503. */
+NDL_API float ndl_pq_distance_with_table(const float *table, const uint8_t *codes, size_t m) {
+    float dist = 0.0f;
+    for (size_t s = 0; s < m; ++s) dist += table[s * 256 + codes[s]];
+    return sqrtf(dist);
+}
+
+/*
+ * ADC scans (the flat form of the quantized scoring named by the hot path):
+ * every row's asymmetric distance, k nearest by (distance, id).
+ *   kind 0: ScalarQuantizer::asymmetric_distance over u8[N][dim]
+ *   kind 1: ProductQuantizer table scan: compute_distance_table once per
+ *           query, distance_with_table per row, over u8[N][m]
+ */
+typedef struct {
+    int kind; const float *queries; size_t nq, dim; const uint8_t *codes; uint64_t n;
+    const float *p0, *p1; size_t m, k; const uint32_t *valid;
+    uint64_t *out_ids; float *out_dists; uint32_t *out_counts;
+    size_t next; pthread_mutex_t mu;
+} adc_job;
+static void *adc_worker(void *arg) {
+    adc_job *jb = (adc_job *)arg;
+    float *table = jb->kind == 1 ? (float *)malloc(sizeof(float) * jb->m * 256) : NULL;
+    for (;;) {
+        pthread_mutex_lock(&jb->mu);
+        size_t q = jb->next++;
+        pthread_mutex_unlock(&jb->mu);
+        if (q >= jb->nq) break;
+        const float *query = jb->queries + q * jb->dim;
+        ndl_heap hp; hp.n = 0; hp.cap = jb->k;
+        hp.h = (ndl_hit *)malloc(sizeof(ndl_hit) * (jb->k + 1));
+        if (jb->kind == 1) ndl_pq_distance_table(query, jb->dim, jb->m, jb->p0, table);
+        for (uint64_t i = 0; i < jb->n && jb->k; ++i) {
+            if (jb->valid && !bit_get(jb->valid, i)) continue;
+            ndl_hit x; x.id = i;
+            if (jb->kind == 0) x.d = ndl_sq_asymmetric(query, jb->codes + i * jb->dim, jb->dim, jb->p0, jb->p1);
+            else x.d = ndl_pq_distance_with_table(table, jb->codes + i * jb->m, jb->m);
+            heap_offer(&hp, x);
+        }
+        qsort(hp.h, hp.n, sizeof(ndl_hit), hit_cmp);
+        for (size_t j = 0; j < hp.n; ++j) {
+            jb->out_ids[q * jb->k + j] = hp.h[j].id;
+            jb->out_dists[q * jb->k + j] = hp.h[j].d;
+        }
+        jb->out_counts[q] = (uint32_t)hp.n;
+        free(hp.h);
+    }
+    free(table);
+    return NULL;
+}
+static void adc_run(adc_job *jb, int threads) {
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > jb->nq) threads = jb->nq ? (int)jb->nq : 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    for (int t = 1; t < threads; ++t) pthread_create(&th[t], NULL, adc_worker, jb);
+    adc_worker(jb);
+    for (int t = 1; t < threads; ++t) pthread_join(th[t], NULL);
+    free(th);
+}
+NDL_API void ndl_sq_batch_search(const float *queries, size_t nq, size_t dim,
+                                 const uint8_t *codes, uint64_t n, const float *min_vals,
+                                 const float *scale, size_t k, const uint32_t *valid,
+                                 int threads, uint64_t *out_ids, float *out_dists,
+                                 uint32_t *out_counts) {
+    adc_job jb = {0, queries, nq, dim, codes, n, min_vals, scale, 0, k, valid,
+                  out_ids, out_dists, out_counts, 0, PTHREAD_MUTEX_INITIALIZER};
+    adc_run(&jb, threads);
+}
+NDL_API void ndl_pq_batch_search(const float *queries, size_t nq, size_t dim,
+                                 const uint8_t *codes, uint64_t n, size_t m,
+                                 const float *codebooks, size_t k, const uint32_t *valid,
+                                 int threads, uint64_t *out_ids, float *out_dists,
+                                 uint32_t *out_counts) {
+    adc_job jb = {1, queries, nq, dim, codes, n, codebooks, NULL, m, k, valid,
+                  out_ids, out_dists, out_counts, 0, PTHREAD_MUTEX_INITIALIZER};
+    adc_run(&jb, threads);
+}

@@ -1,0 +1,527 @@
+"""ctypes front-end for the CPU oracle (oracle/needle_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; the shipped package (needle_amd/) never imports it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libneedle_oracle.so")
+
+COSINE, COSINE_NORMALIZED, EUCLIDEAN, DOT_PRODUCT, MANHATTAN, HAMMING, CHEBYSHEV = range(7)
+ACCEL_COSINE, ACCEL_EUCLIDEAN, ACCEL_DOT = range(3)
+
+_f32p = C.POINTER(C.c_float)
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+_u8p = C.POINTER(C.c_uint8)
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc if the shared object is missing or stale."""
+    src = os.path.join(_HERE, "needle_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libneedle_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(L: C.CDLL) -> None:
+    sz = C.c_size_t
+    for name in ("ndl_dot", "ndl_euclidean_squared", "ndl_euclidean", "ndl_cosine", "ndl_cosine_normalized",
+                 "ndl_dot_distance", "ndl_manhattan", "ndl_hamming", "ndl_chebyshev", "ndl_dot_chunk4",
+                 "ndl_euclidean_chunk4"):
+        f = getattr(L, name)
+        f.restype = C.c_float
+        f.argtypes = [_f32p, _f32p, sz]
+    L.ndl_compute.restype = C.c_float
+    L.ndl_compute.argtypes = [C.c_int, _f32p, _f32p, sz]
+    L.ndl_cosine_chunk4_precomputed.restype = C.c_float
+    L.ndl_cosine_chunk4_precomputed.argtypes = [_f32p, _f32p, sz, C.c_float]
+    L.ndl_normalize.restype = None
+    L.ndl_normalize.argtypes = [_f32p, sz]
+    L.ndl_metric_from_str.restype = C.c_int
+    L.ndl_metric_from_str.argtypes = [C.c_char_p]
+    L.ndl_validate_vector.restype = C.c_int
+    L.ndl_validate_vector.argtypes = [_f32p, sz, C.POINTER(sz)]
+    L.ndl_flat_batch_search.restype = None
+    L.ndl_flat_batch_search.argtypes = [_f32p, sz, _f32p, C.c_uint64, sz, sz, C.c_int, _u32p, _u32p, C.c_int,
+                                        C.c_int, _u64p, _f32p, _u32p]
+    L.ndl_recall.restype = C.c_double
+    L.ndl_recall.argtypes = [_u64p, sz, _u64p, sz, sz]
+    L.ndl_percentile.restype = C.c_double
+    L.ndl_percentile.argtypes = [C.POINTER(C.c_double), sz, C.c_double]
+    L.ndl_gen_vectors.restype = None
+    L.ndl_gen_vectors.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, sz, _f32p]
+    L.ndl_accel_distances.restype = None
+    L.ndl_accel_distances.argtypes = [_f32p, _f32p, sz, sz, C.c_int, _f32p]
+    L.ndl_accel_batch_distance.restype = None
+    L.ndl_accel_batch_distance.argtypes = [_f32p, _f32p, sz, sz, C.c_int, _f32p]
+    L.ndl_top_k.restype = sz
+    L.ndl_top_k.argtypes = [_f32p, sz, sz, _u64p, _f32p]
+    L.ndl_accel_fused_search.restype = sz
+    L.ndl_accel_fused_search.argtypes = [_f32p, _f32p, sz, sz, sz, C.c_int, _u64p, _f32p]
+    L.ndl_accel_batch_fused_search.restype = None
+    L.ndl_accel_batch_fused_search.argtypes = [_f32p, sz, _f32p, sz, sz, sz, C.c_int, C.c_int, _u64p, _f32p, _u32p]
+    L.ndl_accel_streaming_search.restype = sz
+    L.ndl_accel_streaming_search.argtypes = [_f32p, _f32p, sz, sz, sz, C.c_int, sz, _u64p, _f32p]
+    L.ndl_accel_kmeans_assign.restype = None
+    L.ndl_accel_kmeans_assign.argtypes = [_f32p, sz, _f32p, sz, sz, _u64p]
+    L.ndl_merge_topk.restype = sz
+    L.ndl_merge_topk.argtypes = [_f32p, _u64p, _u32p, sz, sz, sz, _u64p, _f32p]
+    L.ndl_ivf_nearest_centroid.restype = C.c_uint32
+    L.ndl_ivf_nearest_centroid.argtypes = [_f32p, _f32p, sz, sz]
+    L.ndl_ivf_assign.restype = None
+    L.ndl_ivf_assign.argtypes = [_f32p, sz, _f32p, sz, sz, C.c_int, _u32p]
+    L.ndl_ivf_probe.restype = sz
+    L.ndl_ivf_probe.argtypes = [_f32p, _f32p, sz, sz, sz, _u32p]
+    L.ndl_ivf_batch_search.restype = None
+    L.ndl_ivf_batch_search.argtypes = [_f32p, sz, _f32p, sz, _f32p, sz, _u64p, _u64p, sz, sz, C.c_int, _u8p, _f32p,
+                                       sz, C.c_int, _u64p, _f32p, _u32p]
+    L.ndl_ivf_kmeans.restype = sz
+    L.ndl_ivf_kmeans.argtypes = [_f32p, sz, sz, sz, sz, C.c_float, C.c_uint64, _f32p]
+    L.ndl_sq_train.restype = C.c_float
+    L.ndl_sq_train.argtypes = [_f32p, sz, sz, _f32p, _f32p, _f32p]
+    L.ndl_sq_quantize_batch.restype = None
+    L.ndl_sq_quantize_batch.argtypes = [_f32p, sz, sz, _f32p, _f32p, _u8p]
+    L.ndl_sq_dequantize.restype = None
+    L.ndl_sq_dequantize.argtypes = [_u8p, sz, _f32p, _f32p, _f32p]
+    L.ndl_sq_asymmetric.restype = C.c_float
+    L.ndl_sq_asymmetric.argtypes = [_f32p, _u8p, sz, _f32p, _f32p]
+    L.ndl_sq_distance_squared.restype = C.c_float
+    L.ndl_sq_distance_squared.argtypes = [_u8p, _u8p, sz, C.c_float]
+    L.ndl_pq_train.restype = None
+    L.ndl_pq_train.argtypes = [_f32p, sz, sz, sz, C.c_uint64, _f32p, _u32p]
+    L.ndl_pq_encode_batch.restype = None
+    L.ndl_pq_encode_batch.argtypes = [_f32p, sz, sz, sz, _f32p, _u32p, _u8p]
+    L.ndl_pq_decode.restype = None
+    L.ndl_pq_decode.argtypes = [_u8p, sz, sz, _f32p, _f32p]
+    L.ndl_pq_asymmetric.restype = C.c_float
+    L.ndl_pq_asymmetric.argtypes = [_f32p, _u8p, sz, sz, _f32p]
+    L.ndl_pq_distance_table.restype = None
+    L.ndl_pq_distance_table.argtypes = [_f32p, sz, sz, _f32p, _f32p]
+    L.ndl_pq_distance_with_table.restype = C.c_float
+    L.ndl_pq_distance_with_table.argtypes = [_f32p, _u8p, sz]
+    L.ndl_sq_batch_search.restype = None
+    L.ndl_sq_batch_search.argtypes = [_f32p, sz, sz, _u8p, C.c_uint64, _f32p, _f32p, sz, _u32p, C.c_int, _u64p,
+                                      _f32p, _u32p]
+    L.ndl_pq_batch_search.restype = None
+    L.ndl_pq_batch_search.argtypes = [_f32p, sz, sz, _u8p, C.c_uint64, sz, _f32p, sz, _u32p, C.c_int, _u64p, _f32p,
+                                      _u32p]
+
+
+# ----------------------------------------------------------------------------
+# numpy helpers
+# ----------------------------------------------------------------------------
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a: np.ndarray, typ):
+    return a.ctypes.data_as(typ)
+
+
+def _mask_ptr(mask, n):
+    """bool[n] or packed uint32 bitmask -> (keepalive, pointer-or-None)."""
+    if mask is None:
+        return None, None
+    m = np.asarray(mask)
+    if m.dtype == np.bool_:
+        m = pack_bitmask(m)
+    m = np.ascontiguousarray(m, dtype=np.uint32)
+    assert m.size >= (n + 31) // 32
+    return m, _p(m, _u32p)
+
+
+def pack_bitmask(bits) -> np.ndarray:
+    """bool[n] -> uint32[ceil(n/32)], bit i of word i>>5 at position i&31."""
+    b = np.asarray(bits, dtype=np.bool_)
+    n = b.size
+    pad = (-n) % 32
+    if pad:
+        b = np.concatenate([b, np.zeros(pad, dtype=np.bool_)])
+    return np.packbits(b.reshape(-1, 32), axis=1, bitorder="little").view(np.uint32).reshape(-1).copy()
+
+
+def cpu_threads() -> int:
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:  # pragma: no cover
+        return os.cpu_count() or 1
+
+
+# ----------------------------------------------------------------------------
+# scalar distances
+# ----------------------------------------------------------------------------
+def compute(metric: int, a, b) -> float:
+    a, b = _f32(a), _f32(b)
+    if a.size != b.size:
+        raise ValueError(f"Dimension mismatch: expected {a.size}, got {b.size}")
+    return float(lib().ndl_compute(metric, _p(a, _f32p), _p(b, _f32p), a.size))
+
+
+def _pair(name):
+    def f(a, b) -> float:
+        a, b = _f32(a), _f32(b)
+        if a.size != b.size:
+            raise ValueError(f"Dimension mismatch: expected {a.size}, got {b.size}")
+        return float(getattr(lib(), name)(_p(a, _f32p), _p(b, _f32p), a.size))
+    f.__name__ = name
+    return f
+
+
+dot = _pair("ndl_dot")
+euclidean = _pair("ndl_euclidean")
+euclidean_squared = _pair("ndl_euclidean_squared")
+cosine = _pair("ndl_cosine")
+cosine_normalized = _pair("ndl_cosine_normalized")
+dot_distance = _pair("ndl_dot_distance")
+manhattan = _pair("ndl_manhattan")
+hamming = _pair("ndl_hamming")
+chebyshev = _pair("ndl_chebyshev")
+dot_chunk4 = _pair("ndl_dot_chunk4")
+euclidean_chunk4 = _pair("ndl_euclidean_chunk4")
+
+
+def cosine_chunk4_precomputed(a, b, a_norm: float) -> float:
+    a, b = _f32(a), _f32(b)
+    return float(lib().ndl_cosine_chunk4_precomputed(_p(a, _f32p), _p(b, _f32p), a.size, C.c_float(a_norm)))
+
+
+def normalized(v) -> np.ndarray:
+    out = _f32(v).copy()
+    lib().ndl_normalize(_p(out, _f32p), out.size)
+    return out
+
+
+def normalize_rows(m) -> np.ndarray:
+    out = _f32(m).copy()
+    L = lib()
+    for i in range(out.shape[0]):
+        row = out[i]
+        L.ndl_normalize(_p(row, _f32p), row.size)
+    return out
+
+
+def metric_from_str(s: str) -> int:
+    return int(lib().ndl_metric_from_str(s.encode()))
+
+
+def validate_vector(v):
+    v = _f32(v)
+    bad = C.c_size_t(0)
+    rc = lib().ndl_validate_vector(_p(v, _f32p), v.size, C.byref(bad))
+    return rc, int(bad.value)
+
+
+# ----------------------------------------------------------------------------
+# flat search / ground truth
+# ----------------------------------------------------------------------------
+def flat_batch_search(queries, base, k: int, metric: int, valid=None, filt=None, evict_nearest: bool = False,
+                      threads: int | None = None):
+    """Returns (ids[Q,k] uint64, dists[Q,k] float32, counts[Q] uint32)."""
+    q, b = _f32(queries), _f32(base)
+    nq, dim = q.shape
+    n = b.shape[0]
+    assert b.ndim == 2 and (n == 0 or b.shape[1] == dim)
+    kk = max(k, 1)
+    ids = np.full((nq, kk), np.iinfo(np.uint64).max, dtype=np.uint64)
+    dists = np.full((nq, kk), np.inf, dtype=np.float32)
+    counts = np.zeros(nq, dtype=np.uint32)
+    vk, vp = _mask_ptr(valid, n)
+    fk, fp = _mask_ptr(filt, n)
+    if nq and k:
+        lib().ndl_flat_batch_search(_p(q, _f32p), nq, _p(b, _f32p), n, dim, k, metric, vp, fp, int(evict_nearest),
+                                    threads or cpu_threads(), _p(ids, _u64p), _p(dists, _f32p), _p(counts, _u32p))
+    return ids[:, :k], dists[:, :k], counts
+
+
+def recall(ann_ids, gt_ids, k: int) -> float:
+    a = np.ascontiguousarray(ann_ids, dtype=np.uint64)
+    g = np.ascontiguousarray(gt_ids, dtype=np.uint64)
+    return float(lib().ndl_recall(_p(a, _u64p), a.size, _p(g, _u64p), g.size, k))
+
+
+def percentile(sorted_vals, p: float) -> float:
+    s = np.ascontiguousarray(sorted_vals, dtype=np.float64)
+    return float(lib().ndl_percentile(s.ctypes.data_as(C.POINTER(C.c_double)), s.size, p))
+
+
+def gen_vectors(seed: int, first: int, count: int, dim: int) -> np.ndarray:
+    out = np.empty((count, dim), dtype=np.float32)
+    lib().ndl_gen_vectors(seed, first, count, dim, _p(out, _f32p))
+    return out
+
+
+# ----------------------------------------------------------------------------
+# GpuAccelerator CPU arm
+# ----------------------------------------------------------------------------
+def accel_batch_distance(query, base, dtype: int) -> np.ndarray:
+    q, b = _f32(query), _f32(base)
+    out = np.empty(b.shape[0], dtype=np.float32)
+    lib().ndl_accel_batch_distance(_p(q, _f32p), _p(b, _f32p), b.shape[0], q.size, dtype, _p(out, _f32p))
+    return out
+
+
+def top_k(scores, k: int):
+    s = _f32(scores)
+    kk = max(min(k, s.size), 1)
+    idx = np.empty(kk, dtype=np.uint64)
+    val = np.empty(kk, dtype=np.float32)
+    m = lib().ndl_top_k(_p(s, _f32p), s.size, k, _p(idx, _u64p), _p(val, _f32p))
+    return idx[:m], val[:m]
+
+
+def accel_fused_search(query, base, k: int, dtype: int):
+    q, b = _f32(query), _f32(base)
+    kk = max(min(k, b.shape[0]), 1)
+    idx = np.empty(kk, dtype=np.uint64)
+    val = np.empty(kk, dtype=np.float32)
+    m = lib().ndl_accel_fused_search(_p(q, _f32p), _p(b, _f32p), b.shape[0], q.size, min(k, b.shape[0]), dtype,
+                                     _p(idx, _u64p), _p(val, _f32p))
+    return idx[:m], val[:m]
+
+
+def accel_batch_fused_search(queries, base, k: int, dtype: int, threads: int | None = None):
+    q, b = _f32(queries), _f32(base)
+    nq, dim = q.shape
+    n = b.shape[0]
+    k = min(k, n)
+    kk = max(k, 1)
+    idx = np.full((nq, kk), np.iinfo(np.uint64).max, dtype=np.uint64)
+    val = np.full((nq, kk), np.inf, dtype=np.float32)
+    counts = np.zeros(nq, dtype=np.uint32)
+    if nq and n and k:
+        lib().ndl_accel_batch_fused_search(_p(q, _f32p), nq, _p(b, _f32p), n, dim, k, dtype, threads or cpu_threads(),
+                                           _p(idx, _u64p), _p(val, _f32p), _p(counts, _u32p))
+    return idx[:, :k], val[:, :k], counts
+
+
+def accel_streaming_search(query, base, k: int, dtype: int, chunk: int):
+    q, b = _f32(query), _f32(base)
+    kk = max(k, 1)
+    idx = np.empty(kk, dtype=np.uint64)
+    val = np.empty(kk, dtype=np.float32)
+    m = lib().ndl_accel_streaming_search(_p(q, _f32p), _p(b, _f32p), b.shape[0], q.size, k, dtype, chunk,
+                                         _p(idx, _u64p), _p(val, _f32p))
+    return idx[:m], val[:m]
+
+
+def accel_kmeans_assign(vectors, centroids) -> np.ndarray:
+    v, c = _f32(vectors), _f32(centroids)
+    out = np.empty(v.shape[0], dtype=np.uint64)
+    lib().ndl_accel_kmeans_assign(_p(v, _f32p), v.shape[0], _p(c, _f32p), c.shape[0], v.shape[1], _p(out, _u64p))
+    return out
+
+
+def merge_topk(dists, ids, counts, k: int):
+    """dists/ids: [lists, per]; counts: [lists]."""
+    d = _f32(dists)
+    i = np.ascontiguousarray(ids, dtype=np.uint64)
+    c = np.ascontiguousarray(counts, dtype=np.uint32)
+    lists, per = d.shape
+    kk = max(k, 1)
+    oi = np.empty(kk, dtype=np.uint64)
+    od = np.empty(kk, dtype=np.float32)
+    m = lib().ndl_merge_topk(_p(d, _f32p), _p(i, _u64p), _p(c, _u32p), lists, per, k, _p(oi, _u64p), _p(od, _f32p))
+    return oi[:m], od[:m]
+
+
+# ----------------------------------------------------------------------------
+# IVF
+# ----------------------------------------------------------------------------
+def ivf_assign(base, centroids, threads: int | None = None) -> np.ndarray:
+    b, c = _f32(base), _f32(centroids)
+    out = np.empty(b.shape[0], dtype=np.uint32)
+    lib().ndl_ivf_assign(_p(b, _f32p), b.shape[0], _p(c, _f32p), c.shape[0], b.shape[1], threads or cpu_threads(),
+                         _p(out, _u32p))
+    return out
+
+
+def ivf_lists_from_assignment(assign, nlist: int):
+    """CSR inverted lists in insertion (row) order: (offsets[nlist+1], order[N])."""
+    a = np.asarray(assign, dtype=np.int64)
+    order = np.argsort(a, kind="stable").astype(np.uint64)
+    counts = np.bincount(a, minlength=nlist)
+    offsets = np.zeros(nlist + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(counts)
+    return offsets, order
+
+
+def ivf_probe(query, centroids, nprobe: int) -> np.ndarray:
+    q, c = _f32(query), _f32(centroids)
+    out = np.empty(max(min(nprobe, c.shape[0]), 1), dtype=np.uint32)
+    m = lib().ndl_ivf_probe(_p(q, _f32p), _p(c, _f32p), c.shape[0], q.size, nprobe, _p(out, _u32p))
+    return out[:m]
+
+
+def ivf_batch_search(queries, base, centroids, offsets, order, nprobe: int, k: int, evict_nearest: bool = False,
+                     pq_codes=None, pq_codebooks=None, pq_m: int = 0, threads: int | None = None):
+    q, c = _f32(queries), _f32(centroids)
+    b = _f32(base) if base is not None else None
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    od = np.ascontiguousarray(order, dtype=np.uint64)
+    nq, dim = q.shape
+    kk = max(k, 1)
+    ids = np.full((nq, kk), np.iinfo(np.uint64).max, dtype=np.uint64)
+    dists = np.full((nq, kk), np.inf, dtype=np.float32)
+    counts = np.zeros(nq, dtype=np.uint32)
+    codes = np.ascontiguousarray(pq_codes, dtype=np.uint8) if pq_codes is not None else None
+    cbs = _f32(pq_codebooks) if pq_codebooks is not None else None
+    if nq and k:
+        lib().ndl_ivf_batch_search(_p(q, _f32p), nq, _p(b, _f32p) if b is not None else None, dim, _p(c, _f32p),
+                                   c.shape[0], _p(off, _u64p), _p(od, _u64p), nprobe, k, int(evict_nearest),
+                                   _p(codes, _u8p) if codes is not None else None,
+                                   _p(cbs, _f32p) if cbs is not None else None, pq_m, threads or cpu_threads(),
+                                   _p(ids, _u64p), _p(dists, _f32p), _p(counts, _u32p))
+    return ids[:, :k], dists[:, :k], counts
+
+
+def ivf_kmeans(vectors, nlist: int, max_iter: int = 100, tol: float = 1e-4, seed: int = 1) -> np.ndarray:
+    v = _f32(vectors)
+    n, dim = v.shape
+    cents = np.zeros((min(nlist, n), dim), dtype=np.float32)
+    k = lib().ndl_ivf_kmeans(_p(v, _f32p), n, dim, nlist, max_iter, C.c_float(tol), seed, _p(cents, _f32p))
+    return cents[:k]
+
+
+# ----------------------------------------------------------------------------
+# quantizers
+# ----------------------------------------------------------------------------
+class ScalarQuantizer:
+    """ScalarQuantizer of src/indexing/quantization.rs:135-286."""
+
+    def __init__(self, min_vals, max_vals, scale, avg_scale):
+        self.min_vals, self.max_vals, self.scale, self.avg_scale = min_vals, max_vals, scale, avg_scale
+        self.dimensions = min_vals.size
+
+    @classmethod
+    def train(cls, vectors):
+        v = _f32(vectors)
+        n, dim = v.shape
+        mn = np.empty(dim, dtype=np.float32)
+        mx = np.empty(dim, dtype=np.float32)
+        sc = np.empty(dim, dtype=np.float32)
+        avg = lib().ndl_sq_train(_p(v, _f32p), n, dim, _p(mn, _f32p), _p(mx, _f32p), _p(sc, _f32p))
+        return cls(mn, mx, sc, float(avg))
+
+    def quantize(self, vectors) -> np.ndarray:
+        v = _f32(vectors)
+        single = v.ndim == 1
+        v2 = v.reshape(1, -1) if single else v
+        out = np.empty(v2.shape, dtype=np.uint8)
+        lib().ndl_sq_quantize_batch(_p(v2, _f32p), v2.shape[0], v2.shape[1], _p(self.min_vals, _f32p),
+                                    _p(self.scale, _f32p), _p(out, _u8p))
+        return out[0] if single else out
+
+    def dequantize(self, codes) -> np.ndarray:
+        c = np.ascontiguousarray(codes, dtype=np.uint8)
+        out = np.empty(c.size, dtype=np.float32)
+        lib().ndl_sq_dequantize(_p(c, _u8p), c.size, _p(self.min_vals, _f32p), _p(self.scale, _f32p), _p(out, _f32p))
+        return out
+
+    def asymmetric_distance(self, query, codes) -> float:
+        q = _f32(query)
+        c = np.ascontiguousarray(codes, dtype=np.uint8)
+        return float(lib().ndl_sq_asymmetric(_p(q, _f32p), _p(c, _u8p), q.size, _p(self.min_vals, _f32p),
+                                             _p(self.scale, _f32p)))
+
+    def distance_squared(self, a, b) -> float:
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        b = np.ascontiguousarray(b, dtype=np.uint8)
+        return float(lib().ndl_sq_distance_squared(_p(a, _u8p), _p(b, _u8p), a.size, C.c_float(self.avg_scale)))
+
+    def batch_search(self, queries, codes, k: int, valid=None, threads: int | None = None):
+        q = _f32(queries)
+        c = np.ascontiguousarray(codes, dtype=np.uint8)
+        nq, dim = q.shape
+        n = c.shape[0]
+        kk = max(k, 1)
+        ids = np.full((nq, kk), np.iinfo(np.uint64).max, dtype=np.uint64)
+        dists = np.full((nq, kk), np.inf, dtype=np.float32)
+        counts = np.zeros(nq, dtype=np.uint32)
+        vk, vp = _mask_ptr(valid, n)
+        lib().ndl_sq_batch_search(_p(q, _f32p), nq, dim, _p(c, _u8p), n, _p(self.min_vals, _f32p),
+                                  _p(self.scale, _f32p), k, vp, threads or cpu_threads(), _p(ids, _u64p),
+                                  _p(dists, _f32p), _p(counts, _u32p))
+        return ids[:, :k], dists[:, :k], counts
+
+
+class ProductQuantizer:
+    """ProductQuantizer of src/indexing/quantization.rs:317-504 (seeded training)."""
+
+    def __init__(self, codebooks, ncent, dim, m):
+        self.codebooks, self.ncent, self.dim, self.m = codebooks, ncent, dim, m
+        self.dsub = dim // m
+
+    @classmethod
+    def train(cls, vectors, m: int, seed: int = 1):
+        v = _f32(vectors)
+        n, dim = v.shape
+        cb = np.zeros((m, 256, dim // m), dtype=np.float32)
+        nc = np.zeros(m, dtype=np.uint32)
+        lib().ndl_pq_train(_p(v, _f32p), n, dim, m, seed, _p(cb, _f32p), _p(nc, _u32p))
+        return cls(cb, nc, dim, m)
+
+    def encode(self, vectors) -> np.ndarray:
+        v = _f32(vectors)
+        single = v.ndim == 1
+        v2 = v.reshape(1, -1) if single else v
+        out = np.empty((v2.shape[0], self.m), dtype=np.uint8)
+        lib().ndl_pq_encode_batch(_p(v2, _f32p), v2.shape[0], self.dim, self.m, _p(self.codebooks, _f32p),
+                                  _p(self.ncent, _u32p), _p(out, _u8p))
+        return out[0] if single else out
+
+    def decode(self, codes) -> np.ndarray:
+        c = np.ascontiguousarray(codes, dtype=np.uint8)
+        out = np.empty(self.m * self.dsub, dtype=np.float32)
+        lib().ndl_pq_decode(_p(c, _u8p), self.dim, self.m, _p(self.codebooks, _f32p), _p(out, _f32p))
+        return out
+
+    def asymmetric_distance(self, query, codes) -> float:
+        q = _f32(query)
+        c = np.ascontiguousarray(codes, dtype=np.uint8)
+        return float(lib().ndl_pq_asymmetric(_p(q, _f32p), _p(c, _u8p), self.dim, self.m, _p(self.codebooks, _f32p)))
+
+    def compute_distance_table(self, query) -> np.ndarray:
+        q = _f32(query)
+        t = np.empty((self.m, 256), dtype=np.float32)
+        lib().ndl_pq_distance_table(_p(q, _f32p), self.dim, self.m, _p(self.codebooks, _f32p), _p(t, _f32p))
+        return t
+
+    def distance_with_table(self, table, codes) -> float:
+        t = _f32(table)
+        c = np.ascontiguousarray(codes, dtype=np.uint8)
+        return float(lib().ndl_pq_distance_with_table(_p(t, _f32p), _p(c, _u8p), self.m))
+
+    def batch_search(self, queries, codes, k: int, valid=None, threads: int | None = None):
+        q = _f32(queries)
+        c = np.ascontiguousarray(codes, dtype=np.uint8)
+        nq, dim = q.shape
+        n = c.shape[0]
+        kk = max(k, 1)
+        ids = np.full((nq, kk), np.iinfo(np.uint64).max, dtype=np.uint64)
+        dists = np.full((nq, kk), np.inf, dtype=np.float32)
+        counts = np.zeros(nq, dtype=np.uint32)
+        vk, vp = _mask_ptr(valid, n)
+        lib().ndl_pq_batch_search(_p(q, _f32p), nq, dim, _p(c, _u8p), n, self.m, _p(self.codebooks, _f32p), k, vp,
+                                  threads or cpu_threads(), _p(ids, _u64p), _p(dists, _f32p), _p(counts, _u32p))
+        return ids[:, :k], dists[:, :k], counts

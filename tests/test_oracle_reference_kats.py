@@ -1,0 +1,374 @@
+"""Pins the CPU oracle against the reference's own known-answer tests.
+
+Every case restates an assertion of a `#[test]` in the reference (cited per
+test).  These are the only value-pinning tests the reference holds for the
+batched-search path; passing them is what licenses using the oracle as the
+checker for the HIP kernels.
+"""
+import math
+
+import numpy as np
+import pytest
+
+F = np.float32
+
+
+# ---------------------------------------------------------------- distance.rs
+def test_dot_product(oracle):  # src/distance.rs:862-867
+    assert abs(oracle.dot([1, 2, 3, 4], [5, 6, 7, 8]) - 70.0) < 1e-6
+
+
+def test_euclidean_distance(oracle):  # src/distance.rs:870-875
+    assert abs(oracle.euclidean([0, 0, 0], [1, 2, 2]) - 3.0) < 1e-6
+
+
+def test_cosine_distance(oracle):  # src/distance.rs:878-888
+    assert abs(oracle.cosine([1, 0], [0, 1]) - 1.0) < 1e-6
+    assert abs(oracle.cosine([1, 0], [1, 0])) < 1e-6
+
+
+def test_manhattan_distance(oracle):  # src/distance.rs:891-896
+    assert abs(oracle.manhattan([0, 0, 0], [1, 2, 3]) - 6.0) < 1e-6
+
+
+def test_normalize(oracle):  # src/distance.rs:899-904
+    v = oracle.normalized([3.0, 4.0])
+    assert abs(v[0] - 0.6) < 1e-6 and abs(v[1] - 0.8) < 1e-6
+
+
+def test_cosine_distance_normalized(oracle):  # src/distance.rs:907-939
+    a, b = oracle.normalized([1, 0]), oracle.normalized([0, 1])
+    assert abs(oracle.cosine_normalized(a, b) - 1.0) < 1e-6
+    assert abs(oracle.cosine_normalized(a, a)) < 1e-6
+    v1, v2 = oracle.normalized([1, 2, 3]), oracle.normalized([4, 5, 6])
+    assert abs(oracle.cosine(v1, v2) - oracle.cosine_normalized(v1, v2)) < 1e-5
+    a4, b4 = oracle.normalized([1, 2, 3, 4]), oracle.normalized([5, 6, 7, 8])
+    assert abs(oracle.compute(oracle.COSINE, a4, b4) - oracle.compute(oracle.COSINE_NORMALIZED, a4, b4)) < 1e-5
+
+
+def test_dimension_mismatch(oracle):  # src/distance.rs:946-973
+    for m in range(5):
+        with pytest.raises(ValueError):
+            oracle.compute(m, [1, 2, 3], [1, 2])
+
+
+def test_zero_vector_cosine(oracle):  # src/distance.rs:985-1000
+    assert abs(oracle.cosine([0, 0, 0], [1, 2, 3]) - 1.0) < 1e-6
+    assert abs(oracle.cosine([0, 0], [0, 0]) - 1.0) < 1e-6
+
+
+def test_nan_inf_propagation(oracle):  # src/distance.rs:1003-1034
+    assert math.isnan(oracle.euclidean([np.nan, 1], [1, 2]))
+    assert math.isnan(oracle.dot([np.nan, 1], [1, 2]))
+    assert math.isinf(oracle.euclidean([np.inf, 0], [0, 1]))
+    assert math.isinf(oracle.manhattan([np.inf, 0], [0, 1]))
+    assert math.isinf(oracle.manhattan([-np.inf, 0], [0, 1]))
+
+
+def test_identical_vectors(oracle):  # src/distance.rs:1037-1052
+    a = [1, 2, 3]
+    assert abs(oracle.cosine(a, a)) < 1e-6
+    assert abs(oracle.euclidean(a, a)) < 1e-6
+    assert abs(oracle.manhattan(a, a)) < 1e-6
+    assert abs(oracle.euclidean_squared(a, a)) < 1e-6
+
+
+def test_single_dimension(oracle):  # src/distance.rs:1055-1064
+    assert abs(oracle.euclidean([3], [7]) - 4.0) < 1e-6
+    assert abs(oracle.manhattan([3], [7]) - 4.0) < 1e-6
+
+
+def test_dot_distance_negation(oracle):  # src/distance.rs:1067-1074
+    a, b = [1, 2, 3], [4, 5, 6]
+    assert abs(oracle.dot_distance(a, b) + oracle.dot(a, b)) < 1e-6
+
+
+def test_normalize_zero(oracle):  # src/distance.rs:1077-1082
+    assert np.all(oracle.normalized([0, 0, 0]) == 0)
+
+
+def test_compute_dispatch(oracle):  # src/distance.rs:1093-1111
+    a, b = [1, 0, 0], [0, 1, 0]
+    assert abs(oracle.compute(oracle.COSINE, a, b) - 1.0) < 1e-6
+    assert abs(oracle.compute(oracle.EUCLIDEAN, a, b) - math.sqrt(2)) < 1e-5
+    assert abs(oracle.compute(oracle.DOT_PRODUCT, a, b)) < 1e-6
+    assert abs(oracle.compute(oracle.MANHATTAN, a, b) - 2.0) < 1e-6
+    assert abs(oracle.compute(oracle.COSINE_NORMALIZED, a, b) - 1.0) < 1e-6
+
+
+def test_hamming_chebyshev_doc_examples(oracle):  # src/distance.rs:381-384, 409-412
+    assert oracle.hamming([1, 0, 1, 0], [1, 1, 0, 0]) == 2.0
+    assert abs(oracle.chebyshev([1, 5, 3], [4, 2, 3]) - 3.0) < 1e-6
+
+
+def test_from_str_aliases(oracle):  # src/distance.rs:132-145
+    o = oracle
+    table = {"cosine": o.COSINE, "COSINE": o.COSINE, "cosine_normalized": o.COSINE_NORMALIZED,
+             "CosineNormalized": o.COSINE_NORMALIZED, "euclidean": o.EUCLIDEAN, "l2": o.EUCLIDEAN, "L2": o.EUCLIDEAN,
+             "dot": o.DOT_PRODUCT, "dotproduct": o.DOT_PRODUCT, "dot_product": o.DOT_PRODUCT,
+             "inner_product": o.DOT_PRODUCT, "manhattan": o.MANHATTAN, "l1": o.MANHATTAN, "hamming": o.HAMMING,
+             "chebyshev": o.CHEBYSHEV, "linf": o.CHEBYSHEV, "l_inf": o.CHEBYSHEV, "l_infinity": o.CHEBYSHEV}
+    for s, m in table.items():
+        assert o.metric_from_str(s) == m, s
+    assert o.metric_from_str("bogus") == -1
+
+
+def test_validate_vector(oracle):  # src/collection/validation.rs:88-114
+    assert oracle.validate_vector([1, 2, 3])[0] == 0
+    assert oracle.validate_vector([])[0] == 0
+    assert oracle.validate_vector([1, np.nan, 3]) == (1, 1)
+    assert oracle.validate_vector([np.inf, 0]) == (2, 0)
+    assert oracle.validate_vector([0, -np.inf]) == (2, 1)
+    assert oracle.validate_vector([0, 0, 0])[0] == 0
+
+
+# ------------------------------------------------- experimental/gpu/mod.rs
+def test_batch_cosine(oracle):  # gpu/mod.rs:1597-1613
+    d = oracle.accel_batch_distance([1, 0, 0], [[1, 0, 0], [0, 1, 0], [-1, 0, 0]], oracle.ACCEL_COSINE)
+    assert np.allclose(d, [0, 1, 2], atol=1e-6)
+
+
+def test_batch_euclidean(oracle):  # gpu/mod.rs:1616-1632
+    d = oracle.accel_batch_distance([0, 0, 0], [[1, 0, 0], [0, 2, 0], [3, 4, 0]], oracle.ACCEL_EUCLIDEAN)
+    assert np.allclose(d, [1, 2, 5], atol=1e-6)
+
+
+def test_batch_dot(oracle):  # gpu/mod.rs:1635-1651
+    d = oracle.accel_batch_distance([1, 2, 3], [[1, 0, 0], [0, 1, 0], [1, 1, 1]], oracle.ACCEL_DOT)
+    assert np.allclose(d, [1, 2, 6], atol=1e-6)
+
+
+def test_batch_top_k(oracle):  # gpu/mod.rs:1669-1679
+    idx, _ = oracle.top_k([0.5, 0.1, 0.8, 0.3, 0.2], 3)
+    assert idx.tolist() == [1, 4, 3]
+
+
+def test_partial_sort_top_k(oracle):  # gpu/mod.rs:1964-1972
+    idx, _ = oracle.top_k([0.5, 0.1, 0.8, 0.3, 0.2, 0.9, 0.15], 3)
+    assert idx.tolist() == [1, 6, 4]
+
+
+def test_kmeans_assign(oracle):  # gpu/mod.rs:1722-1737
+    a = oracle.accel_kmeans_assign([[0, 0], [0.1, 0.1], [10, 10], [10.1, 10.1]], [[0, 0], [10, 10]])
+    assert a.tolist() == [0, 0, 1, 1]
+
+
+def test_kmeans_assign_large(oracle):  # gpu/mod.rs:1917-1940
+    v = np.array([[i * 0.001, 0.0] if i < 250 else [10.0 + (i - 250) * 0.001, 10.0] for i in range(500)], dtype=F)
+    a = oracle.accel_kmeans_assign(v, [[0, 0], [10, 10]])
+    assert np.all(a[:250] == 0) and np.all(a[250:] == 1)
+
+
+def test_fused_search(oracle):  # gpu/mod.rs:1740-1758
+    idx, _ = oracle.accel_fused_search([1, 0, 0], [[1, 0, 0], [0.9, 0.1, 0], [0, 1, 0], [-1, 0, 0]], 2,
+                                       oracle.ACCEL_COSINE)
+    assert idx.tolist() == [0, 1]
+
+
+def test_batch_fused_search(oracle):  # gpu/mod.rs:1876-1900
+    q = [[1, 0, 0], [0, 1, 0], [0, 0, 1]]
+    b = [[1, 0, 0], [0, 1, 0], [0, 0, 1], [0.5, 0.5, 0]]
+    idx, _, counts = oracle.accel_batch_fused_search(q, b, 2, oracle.ACCEL_COSINE)
+    assert idx.shape == (3, 2) and counts.tolist() == [2, 2, 2]
+    assert idx[:, 0].tolist() == [0, 1, 2]
+
+
+def test_cosine_precomputed(oracle):  # gpu/mod.rs:1975-1986
+    assert abs(oracle.cosine_chunk4_precomputed([1, 0, 0], [1, 0, 0], 1.0)) < 1e-6
+    assert abs(oracle.cosine_chunk4_precomputed([1, 0, 0], [0, 1, 0], 1.0) - 1.0) < 1e-6
+
+
+def test_streaming_batch_search(oracle):  # gpu/mod.rs:1991-2019
+    base = np.zeros((500, 3), dtype=F)
+    base[np.arange(500), np.arange(500) % 3] = 1.0
+    idx, d = oracle.accel_streaming_search([1, 0, 0], base, 10, oracle.ACCEL_COSINE, 100)
+    assert len(idx) == 10 and d[0] < 0.01 and np.all(np.diff(d) >= 0)
+
+
+def test_prefiltered_search_semantics(oracle):  # gpu/mod.rs:2067-2091 (filter -> compact -> search -> map back)
+    base = np.array([[1, 0, 0], [0, 1, 0], [0.9, 0.1, 0], [0, 0, 1], [0.8, 0.2, 0]], dtype=F)
+    keep = np.arange(5) % 2 == 0
+    ids, _, counts = oracle.flat_batch_search(np.array([[1, 0, 0]], dtype=F), base, 3, oracle.COSINE, filt=keep)
+    assert counts[0] == 3 and all(i % 2 == 0 for i in ids[0].tolist())
+    assert ids[0].tolist() == [0, 2, 4]
+
+
+# --------------------------------------------------------- quantization.rs
+def test_scalar_quantizer_roundtrip(oracle):  # quantization.rs:997-1018
+    sq = oracle.ScalarQuantizer.train([[0.0, 0.5, 1.0], [0.2, 0.7, 0.8], [0.1, 0.3, 0.9]])
+    orig = np.array([0.15, 0.4, 0.85], dtype=F)
+    deq = sq.dequantize(sq.quantize(orig))
+    assert np.all(np.abs(orig - deq) < 0.1)
+
+
+def test_scalar_quantizer_clamp(oracle):  # quantization.rs:1155-1167
+    sq = oracle.ScalarQuantizer.train([[0.0, 0.0], [1.0, 1.0]])
+    assert sq.quantize([-100.0, 100.0]).tolist() == [0, 255]
+
+
+def test_scalar_quantizer_constant_dim(oracle):  # quantization.rs:1125-1136
+    sq = oracle.ScalarQuantizer.train([[5.0, 5.0, 5.0], [5.0, 5.0, 5.0]])
+    assert sq.scale.tolist() == [1.0, 1.0, 1.0]
+    assert sq.quantize([5.0, 5.0, 5.0]).tolist() == [0, 0, 0]
+
+
+def test_scalar_distance_squared(oracle):  # quantization.rs:1192-1208
+    sq = oracle.ScalarQuantizer.train([[0.0, 0.0], [1.0, 1.0]])
+    a, b = sq.quantize([0.0, 0.0]), sq.quantize([1.0, 1.0])
+    assert sq.distance_squared(a, b) > 0.0
+    assert abs(sq.distance_squared(a, a)) < np.finfo(F).eps
+
+
+def test_pq_reconstruction(oracle):  # quantization.rs:1021-1050
+    rng = np.random.default_rng(3)
+    v = rng.random((100, 16), dtype=F)
+    pq = oracle.ProductQuantizer.train(v, 4, seed=11)
+    codes = pq.encode(v[0])
+    dec = pq.decode(codes)
+    assert codes.size == 4 and dec.size == 16
+    assert float(np.sqrt(np.sum((v[0] - dec) ** 2))) < 2.0
+
+
+def test_pq_table_matches_asymmetric(oracle):  # quantization.rs:1053-1081
+    rng = np.random.default_rng(5)
+    v = rng.random((50, 8), dtype=F)
+    pq = oracle.ProductQuantizer.train(v, 2, seed=7)
+    q = rng.random(8, dtype=F)
+    table = pq.compute_distance_table(q)
+    for row in v:
+        codes = pq.encode(row)
+        assert abs(pq.asymmetric_distance(q, codes) - pq.distance_with_table(table, codes)) < 1e-5
+
+
+# ------------------------------------------------------------------ ivf.rs
+def _ivf(oracle, n, dim, nlist, seed):
+    rng = np.random.default_rng(seed)
+    v = rng.random((n, dim), dtype=F)  # test_utils.rs:12-15: uniform [0,1)
+    cents = oracle.ivf_kmeans(v, nlist, max_iter=100, tol=1e-4, seed=seed)
+    assign = oracle.ivf_assign(v, cents)
+    offsets, order = oracle.ivf_lists_from_assignment(assign, cents.shape[0])
+    return v, cents, assign, offsets, order
+
+
+def test_ivf_insert_and_search(oracle):  # ivf.rs:729-765
+    v, cents, _, offsets, order = _ivf(oracle, 100, 32, 4, 1)
+    assert cents.shape[0] == 4
+    ids, d, counts = oracle.ivf_batch_search(v[:1], v, cents, offsets, order, nprobe=4, k=100)
+    assert counts[0] == 100
+    pos = ids[0].tolist().index(0)
+    assert d[0][pos] < 0.1 and d[0][0] < 1.0
+
+
+def test_ivf_cluster_sizes_sum(oracle):  # ivf.rs:788-805
+    _, cents, _, offsets, _ = _ivf(oracle, 50, 16, 4, 2)
+    assert cents.shape[0] == 4 and int(offsets[-1]) == 50
+
+
+def test_ivf_clusters_capped_at_n(oracle):  # ivf.rs:909-921
+    rng = np.random.default_rng(4)
+    v = rng.random((3, 8), dtype=F)
+    assert oracle.ivf_kmeans(v, 10, seed=3).shape[0] <= 3
+
+
+def test_ivf_k_zero(oracle):  # ivf.rs:852-866
+    v, cents, _, offsets, order = _ivf(oracle, 50, 16, 4, 6)
+    ids, _, counts = oracle.ivf_batch_search(v[:1], v, cents, offsets, order, nprobe=4, k=0)
+    assert ids.shape == (1, 0) and counts[0] == 0
+
+
+def test_ivf_pq_search_len(oracle):  # ivf.rs:768-785
+    v, cents, _, offsets, order = _ivf(oracle, 100, 32, 4, 8)
+    pq = oracle.ProductQuantizer.train(v, 4, seed=9)
+    codes = pq.encode(v)
+    ids, _, counts = oracle.ivf_batch_search(v[:1], None, cents, offsets, order, nprobe=2, k=5, pq_codes=codes,
+                                             pq_codebooks=pq.codebooks, pq_m=4)
+    assert counts[0] == 5
+
+
+# -------------------------------------------------------- collection tests
+def test_override_distance_ordering(oracle):  # collection/mod.rs:1189-1223 (n = k = 3)
+    base = np.array([[1, 0, 0], [0.1, 0, 0], [0, 1, 0]], dtype=F)  # unit_x, small, unit_y
+    q = np.array([[1, 0, 0]], dtype=F)
+    ids, _, _ = oracle.flat_batch_search(q, base, 3, oracle.EUCLIDEAN)
+    assert ids[0][0] == 0  # euclidean: unit_x first
+    ids, _, _ = oracle.flat_batch_search(q, base, 3, oracle.DOT_PRODUCT)
+    assert ids[0][0] == 0
+
+
+def test_batch_shape_sorted_and_clamp(oracle):  # collection/mod.rs:477-500, batch.rs:221-246
+    rng = np.random.default_rng(0)
+    base = rng.random((20, 8), dtype=F)
+    q = rng.random((3, 8), dtype=F)
+    ids, d, counts = oracle.flat_batch_search(q, base, 5, oracle.COSINE)
+    assert ids.shape == (3, 5) and np.all(np.diff(d, axis=1) >= 0)
+    ids, d, counts = oracle.flat_batch_search(q, base, 100, oracle.COSINE)  # clamp_k
+    assert counts.tolist() == [20, 20, 20]
+    ids, d, counts = oracle.flat_batch_search(q, base, 0, oracle.COSINE)  # k = 0
+    assert ids.shape == (3, 0)
+    ids, d, counts = oracle.flat_batch_search(q, np.zeros((0, 8), dtype=F), 5, oracle.COSINE)  # empty collection
+    assert counts.tolist() == [0, 0, 0]
+
+
+# ----------------------------------------------------- recall_benchmark.rs
+def test_gen_vector_deterministic_and_range(oracle):  # recall_benchmark.rs:589-596
+    a = oracle.gen_vectors(42, 7, 1, 64)
+    b = oracle.gen_vectors(42, 7, 1, 64)
+    assert np.array_equal(a, b)
+    assert not np.array_equal(a, oracle.gen_vectors(42, 8, 1, 64))
+    # first element restated by hand from the LCG of recall_benchmark.rs:173-176
+    mask = (1 << 64) - 1
+    state = (42 * 6364136223846793005 + 7) & mask
+    state = (state * 6364136223846793005 + 1442695040888963407) & mask
+    val = F(F(F(state >> 33) / F(4294967295)) * F(2.0)) - F(1.0)
+    assert a[0, 0] == val
+
+
+def test_recall(oracle):  # recall_benchmark.rs:599-610
+    assert abs(oracle.recall([1, 2, 9], [1, 2, 3], 3) - 2.0 / 3.0) < 1e-12
+    assert oracle.recall([1, 2, 3], [1, 2, 3], 3) == 1.0
+    assert oracle.recall([], [], 3) == 1.0
+
+
+def test_percentile(oracle):  # recall_benchmark.rs:613-617
+    s = [float(i) for i in range(1, 101)]
+    assert oracle.percentile(s, 0.50) == 50.0
+    assert oracle.percentile(s, 0.99) == 99.0
+    assert oracle.percentile([], 0.5) == 0.0
+
+
+# ------------------------------------------------------ persistence/shard.rs
+def test_merge_shard_results(oracle):  # persistence/shard.rs:1078-1103  (a=0,b=1,c=2,d=3)
+    ids, d = oracle.merge_topk([[0.1, 0.3], [0.2, 0.4]], [[0, 2], [1, 3]], [2, 2], 3)
+    assert ids.tolist() == [0, 1, 2]
+
+
+def test_merge_dedup(oracle):  # persistence/shard.rs:1106-1125
+    ids, d = oracle.merge_topk([[0.1], [0.15]], [[7], [7]], [1, 1], 10)
+    assert ids.tolist() == [7] and d[0] == F(0.1)
+
+
+# -------------------------------------------- semantics pinned by restatement
+def test_flat_is_distance_then_index_order(oracle):
+    """compute_ground_truth (recall_benchmark.rs:183-207) = stable sort by distance over index order."""
+    rng = np.random.default_rng(1)
+    base = rng.standard_normal((300, 16)).astype(F)
+    base[50] = base[10]
+    base[200] = base[10]  # exact duplicates -> ties resolved by index
+    q = base[10:11] + F(0.0)
+    ids, d, _ = oracle.flat_batch_search(q, base, 5, oracle.EUCLIDEAN)
+    assert ids[0][:3].tolist() == [10, 50, 200]
+    ref = np.array([oracle.euclidean(q[0], b) for b in base], dtype=F)
+    order = np.argsort(ref, kind="stable")[:5]
+    assert ids[0].tolist() == order.tolist()
+    assert np.array_equal(d[0], ref[order])
+
+
+def test_evict_nearest_forensic_mode(oracle):
+    """brute_force_search's heap (search_methods.rs:229-234) pops the smallest distance: with n > k it keeps the
+    k FARTHEST rows.  Only reproducible through the explicit forensic switch."""
+    base = np.array([[float(i)] for i in range(10)], dtype=F)
+    q = np.array([[0.0]], dtype=F)
+    near, _, _ = oracle.flat_batch_search(q, base, 3, oracle.EUCLIDEAN)
+    far, _, _ = oracle.flat_batch_search(q, base, 3, oracle.EUCLIDEAN, evict_nearest=True)
+    assert near[0].tolist() == [0, 1, 2]
+    assert far[0].tolist() == [7, 8, 9]
