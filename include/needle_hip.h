@@ -1,0 +1,221 @@
+/*
+ * needle_hip.h -- C ABI of libneedle_hip.so: batched vector search on AMD
+ * MI355X (gfx950) behind the operator boundary of the Needle vector database.
+ *
+ * Every entry point names the reference interface it stands in for
+ * (file:line relative to the reference repository).  Plain pointers and
+ * sizes only; no exceptions cross this boundary; every call returns a
+ * needle_hip_status and leaves a thread-local message for
+ * needle_hip_last_error().
+ *
+ * Ownership: inputs are borrowed for the duration of the call.  Index builds
+ * COPY the caller's data into device memory (the caller keeps its VectorStore,
+ * src/storage.rs:624-629).  Outputs are written into caller-allocated arrays.
+ * Handles are opaque and released by the matching *_destroy / shutdown call.
+ *
+ * Threading: searches on one index serialise on an internal lock (one
+ * workspace per index); builds / mask updates need exclusive access, like the
+ * reference's &mut self methods.
+ */
+#ifndef NEEDLE_HIP_H
+#define NEEDLE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum needle_hip_status {
+    NEEDLE_HIP_OK = 0,
+    /* NeedleError::DimensionMismatch{expected,got}, src/error.rs; raised by
+     * validate_query, src/collection/validation.rs:27-35 */
+    NEEDLE_HIP_ERR_DIMENSION_MISMATCH = 1,
+    /* NeedleError::InvalidVector (NaN / Inf), validation.rs:8-24 */
+    NEEDLE_HIP_ERR_INVALID_VECTOR = 2,
+    NEEDLE_HIP_ERR_INVALID_ARGUMENT = 3,
+    NEEDLE_HIP_ERR_OUT_OF_MEMORY = 4,
+    NEEDLE_HIP_ERR_HIP = 5,          /* a HIP runtime call failed */
+    NEEDLE_HIP_ERR_NOT_TRAINED = 6,  /* IvfError::NotTrained, src/indexing/ivf.rs:79 */
+    NEEDLE_HIP_ERR_UNSUPPORTED = 7,
+    NEEDLE_HIP_ERR_NO_DEVICE = 8
+} needle_hip_status;
+
+/* DistanceFunction, src/distance.rs:43-73 (same order). */
+typedef enum needle_metric {
+    NEEDLE_METRIC_COSINE = 0,
+    NEEDLE_METRIC_COSINE_NORMALIZED = 1,
+    NEEDLE_METRIC_EUCLIDEAN = 2,
+    NEEDLE_METRIC_DOT_PRODUCT = 3,
+    NEEDLE_METRIC_MANHATTAN = 4,
+    NEEDLE_METRIC_HAMMING = 5,
+    NEEDLE_METRIC_CHEBYSHEV = 6
+} needle_metric;
+
+/* Which of the reference's two scalar arithmetics the reported distances
+ * (and therefore the ranking) reproduce bit for bit:
+ *   DISTANCE_RS : src/distance.rs:153-316 sequential sums -- what
+ *                 Collection::search / batch_search / compute_ground_truth use
+ *   ACCEL_CHUNK4: src/experimental/gpu/common.rs:515-581 groups of four --
+ *                 what GpuAccelerator::{batch_*_distance, fused_search} use
+ *                 (cosine / euclidean / dot only) */
+typedef enum needle_arith {
+    NEEDLE_ARITH_DISTANCE_RS = 0,
+    NEEDLE_ARITH_ACCEL_CHUNK4 = 1
+} needle_arith;
+
+/* Arithmetic of the candidate-generating first pass.  The returned ids and
+ * distances never depend on it: every candidate is re-scored in the
+ * reference's scalar order, a per-query error-bound check proves the
+ * candidate set sufficient, and queries that fail it are re-run on the exact
+ * scan.  EXACT_SCAN skips the first pass (every query on the exact scan). */
+typedef enum needle_precision {
+    NEEDLE_PRECISION_FP32 = 0,
+    NEEDLE_PRECISION_BF16 = 1,
+    NEEDLE_PRECISION_EXACT_SCAN = 2
+} needle_precision;
+
+typedef struct needle_hip_ctx needle_hip_ctx;
+typedef struct needle_hip_index needle_hip_index;
+
+typedef struct needle_search_params {
+    uint32_t k;          /* clamped to the live row count, validation.rs:39-41 */
+    uint32_t nprobe;     /* IVF only: IvfConfig::n_probe, ivf.rs:112 */
+    int32_t precision;   /* needle_precision */
+    uint32_t reserved;
+    /* Pre-filter bitmask over internal row ids (bit i of word i>>5 at i&31; set =
+     * row may be returned), NULL = no filter.  Exact pre-filter semantics of
+     * Collection::brute_force_search, src/collection/search_methods.rs:215-223,
+     * and GpuAccelerator::prefiltered_batch_search, gpu/mod.rs:1033-1080.  Host
+     * pointer for needle_hip_batch_search, device pointer for the *_device form. */
+    const uint32_t* filter_bitmask;
+} needle_search_params;
+
+/* GpuMetrics / update_metrics, src/experimental/gpu/common.rs:246-259,
+ * gpu/mod.rs:825-845, restricted to what the device path can count. */
+typedef struct needle_hip_metrics {
+    uint64_t searches;            /* batch search calls */
+    uint64_t queries;             /* queries served */
+    uint64_t fallback_queries;    /* queries re-run on the exact scan */
+    uint64_t scan_launches;       /* first-pass kernel launches timed */
+    double scan_ms_total;         /* device time of those launches (needs profiling on) */
+    double last_scan_ms;
+    double last_search_ms;        /* device time of the last whole search (profiling on) */
+} needle_hip_metrics;
+
+/* ---- context --------------------------------------------------------- */
+
+/* GpuAccelerator::new / with_cpu_fallback, src/experimental/gpu/mod.rs:103-132:
+ * binds one HIP device.  There is NO CPU fallback here: without a usable
+ * device the call fails with NEEDLE_HIP_ERR_NO_DEVICE. */
+needle_hip_status needle_hip_init(int device_id, needle_hip_ctx** out_ctx);
+void needle_hip_shutdown(needle_hip_ctx* ctx);
+
+/* Message of the calling thread's last failing call ("" if none). */
+const char* needle_hip_last_error(void);
+
+/* Library / ABI version (major*10000 + minor*100 + patch). */
+int needle_hip_version(void);
+
+/* When on, the first-pass kernel and the whole search are bracketed by HIP
+ * events on the library's stream (adds a stream sync per search). */
+needle_hip_status needle_hip_set_profiling(needle_hip_ctx* ctx, int on);
+needle_hip_status needle_hip_get_metrics(needle_hip_ctx* ctx, needle_hip_metrics* out);
+needle_hip_status needle_hip_reset_metrics(needle_hip_ctx* ctx);
+
+/* FromStr for DistanceFunction, src/distance.rs:132-145; -1 if unknown. */
+int needle_hip_metric_from_str(const char* name);
+
+/* ---- exact flat index -------------------------------------------------- */
+
+/* Upload of the base set that Collection::search_builder().distance(..) /
+ * brute_force_search scan, src/collection/search_methods.rs:189-271, and that
+ * GpuResidentIndex::{new,add_batch} keep resident, gpu/mod.rs:1102-1160.
+ * base: n x dim row-major f32 host memory.  valid_bitmask: nullable, bit set =
+ * live row (cleared = deleted / expired, search_methods.rs:205-212). */
+needle_hip_status needle_hip_flat_build(needle_hip_ctx* ctx, const float* base, uint64_t n,
+                                        uint32_t dim, needle_metric metric, needle_arith arith,
+                                        const uint32_t* valid_bitmask, needle_hip_index** out);
+
+/* Same, from the reference's own layout: one heap allocation per row
+ * (VectorStore::as_slice() -> &[Vec<f32>], src/storage.rs:689). */
+needle_hip_status needle_hip_flat_build_rows(needle_hip_ctx* ctx, const float* const* rows,
+                                             uint64_t n, uint32_t dim, needle_metric metric,
+                                             needle_arith arith, const uint32_t* valid_bitmask,
+                                             needle_hip_index** out);
+
+/* Same, from a device-resident n x dim row-major f32 array (copied). */
+needle_hip_status needle_hip_flat_build_device(needle_hip_ctx* ctx, const float* d_base,
+                                               uint64_t n, uint32_t dim, needle_metric metric,
+                                               needle_arith arith, const uint32_t* valid_bitmask_host,
+                                               needle_hip_index** out);
+
+/* HnswIndex::delete / is_deleted bookkeeping seen by the scan
+ * (search_methods.rs:205): replace the live-row mask (NULL = all live). */
+needle_hip_status needle_hip_index_set_valid_mask(needle_hip_index* index,
+                                                  const uint32_t* valid_bitmask);
+
+void needle_hip_index_destroy(needle_hip_index* index);
+
+uint64_t needle_hip_index_len(const needle_hip_index* index);        /* Collection::len */
+uint32_t needle_hip_index_dimensions(const needle_hip_index* index); /* config.dimensions */
+
+/* Collection::batch_search, src/collection/batch.rs:32-75 (and, with
+ * params->filter_bitmask, the exact-pre-filter form of batch_search_with_filter
+ * :108-171); GpuAccelerator::batch_fused_search, gpu/mod.rs:790-823.
+ * queries: q x query_dim row-major host f32.  Every query is validated first
+ * (dimension, NaN, Inf) and any failure rejects the whole batch before work
+ * starts, as batch.rs:37-39.  Outputs are [q][k] row-major; row i holds
+ * out_counts[i] = min(k, live filtered rows) hits ascending by (distance, id),
+ * the rest of the row is padded with id UINT64_MAX / distance +inf. */
+needle_hip_status needle_hip_batch_search(needle_hip_index* index, const float* queries,
+                                          uint32_t q, uint32_t query_dim,
+                                          const needle_search_params* params,
+                                          uint64_t* out_ids, float* out_dists,
+                                          uint32_t* out_counts);
+
+/* Device-resident form of the same call: queries / outputs / filter are device
+ * pointers, work is enqueued on the library stream and the call returns after
+ * it completed.  Values are not validated (no NaN / Inf scan). */
+needle_hip_status needle_hip_batch_search_device(needle_hip_index* index, const float* d_queries,
+                                                 uint32_t q, const needle_search_params* params,
+                                                 uint64_t* d_out_ids, float* d_out_dists,
+                                                 uint32_t* d_out_counts);
+
+/* ---- operator-level calls --------------------------------------------- */
+
+/* GpuAccelerator::batch_{cosine,euclidean}_distance / batch_dot_product,
+ * gpu/mod.rs:308-448 (what the reference's three CUDA kernels compute,
+ * src/experimental/gpu/cuda.rs:212-453): one query against n rows.
+ * metric in {COSINE, EUCLIDEAN, DOT_PRODUCT}; the dot product is returned
+ * positive (not negated), as gpu/mod.rs:432.  Host pointers. */
+needle_hip_status needle_hip_batch_distance(needle_hip_ctx* ctx, needle_metric metric,
+                                            needle_arith arith, const float* query,
+                                            const float* base, uint64_t n, uint32_t dim,
+                                            float* out);
+
+/* GpuAccelerator::kmeans_assign, gpu/mod.rs:660-703 (arith ACCEL_CHUNK4) and
+ * IvfIndex::find_nearest_centroid, ivf.rs:453-459 (arith DISTANCE_RS): index of
+ * the first nearest centroid by Euclidean distance.  Host pointers. */
+needle_hip_status needle_hip_kmeans_assign(needle_hip_ctx* ctx, needle_arith arith,
+                                           const float* vectors, uint64_t n,
+                                           const float* centroids, uint32_t n_centroids,
+                                           uint32_t dim, uint32_t* out_assignment);
+
+/* merge_shard_results, src/persistence/shard.rs:622-643, and
+ * MultiGpuShardManager::search's concat-sort-truncate, gpu/mod.rs:1355-1366:
+ * for each of q queries merge `lists` runs of `per` (distance, id) pairs
+ * (layout [lists][q][per], counts [lists][q]) into the k best by
+ * (distance, id), dropping repeated ids.  Device pointers; used after the
+ * all-gather of per-GPU results. */
+needle_hip_status needle_hip_merge_topk_device(needle_hip_ctx* ctx, const float* d_dists,
+                                               const uint64_t* d_ids, const uint32_t* d_counts,
+                                               uint32_t lists, uint32_t q, uint32_t per,
+                                               uint32_t k, uint64_t* d_out_ids,
+                                               float* d_out_dists, uint32_t* d_out_counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEEDLE_HIP_H */

@@ -1,0 +1,739 @@
+// C ABI of libneedle_hip.so (declarations and reference citations:
+// include/needle_hip.h).  Host-side orchestration only; kernels live in
+// flat_scan.hip, flat_post.hip and prep.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <strings.h>
+#include <vector>
+
+#include "nh_common.h"
+#include "nh_kernels.h"
+
+using namespace nh;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static needle_hip_status fail(needle_hip_status st, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail(_e == hipErrorOutOfMemory ? NEEDLE_HIP_ERR_OUT_OF_MEMORY : NEEDLE_HIP_ERR_HIP, \
+                        "HIP error %d (%s) at %s:%d: %s", (int)_e, hipGetErrorString(_e), __FILE__,    \
+                        __LINE__, #expr);                                                      \
+    } while (0)
+
+#define ST_TRY(expr)                              \
+    do {                                          \
+        needle_hip_status _s = (expr);            \
+        if (_s != NEEDLE_HIP_OK) return _s;       \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// objects
+// ---------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+struct needle_hip_ctx {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    bool profiling = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    needle_hip_metrics m{};
+    std::mutex mu;
+    DevBuf scratch[4];  // operator-level calls
+};
+
+enum IndexKind { KIND_FLAT = 0 };
+
+struct needle_hip_index {
+    needle_hip_ctx* ctx = nullptr;
+    int kind = KIND_FLAT;
+    uint64_t n = 0;
+    uint32_t dim = 0, n_pad = 0;
+    int metric = 0, arith = 0;
+    float* d_raw = nullptr;        // [n_pad][dim], padding rows zero
+    float* d_op_f32 = nullptr;     // [n_pad][dpad_f32] (may alias d_raw)
+    bool op_f32_alias = false;
+    uint16_t* d_op_bf16 = nullptr; // [n_pad][dpad_bf16], built on first use
+    uint32_t dpad_f32 = 0, dpad_bf16 = 0;
+    float* d_cinit = nullptr;      // [n_pad] (Euclidean only)
+    float* d_norms = nullptr;      // [n_pad]
+    uint32_t* d_valid = nullptr;   // live-row bitmask or null
+    float max_norm = 0.0f;
+    float min_pos_norm = 0.0f;
+    std::mutex mu;
+    // per-search workspace (grow-only)
+    DevBuf w_qraw, w_qop, w_qn2, w_lists, w_lcnt, w_cand, w_candn, w_tau, w_flagged, w_flagcnt, w_filter;
+    DevBuf x_keys, x_u32, x_u64, x_sel;
+};
+
+static inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+extern "C" int needle_hip_version(void) { return 100; }
+
+extern "C" const char* needle_hip_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int needle_hip_metric_from_str(const char* s) {
+    if (!s) return -1;
+    static const struct { const char* name; int m; } tab[] = {
+        {"cosine", NEEDLE_METRIC_COSINE},
+        {"cosine_normalized", NEEDLE_METRIC_COSINE_NORMALIZED},
+        {"cosinenormalized", NEEDLE_METRIC_COSINE_NORMALIZED},
+        {"euclidean", NEEDLE_METRIC_EUCLIDEAN}, {"l2", NEEDLE_METRIC_EUCLIDEAN},
+        {"dot", NEEDLE_METRIC_DOT_PRODUCT}, {"dotproduct", NEEDLE_METRIC_DOT_PRODUCT},
+        {"dot_product", NEEDLE_METRIC_DOT_PRODUCT}, {"inner_product", NEEDLE_METRIC_DOT_PRODUCT},
+        {"manhattan", NEEDLE_METRIC_MANHATTAN}, {"l1", NEEDLE_METRIC_MANHATTAN},
+        {"hamming", NEEDLE_METRIC_HAMMING},
+        {"chebyshev", NEEDLE_METRIC_CHEBYSHEV}, {"linf", NEEDLE_METRIC_CHEBYSHEV},
+        {"l_inf", NEEDLE_METRIC_CHEBYSHEV}, {"l_infinity", NEEDLE_METRIC_CHEBYSHEV},
+    };
+    for (const auto& t : tab)
+        if (strcasecmp(s, t.name) == 0) return t.m;
+    return -1;
+}
+
+extern "C" needle_hip_status needle_hip_init(int device_id, needle_hip_ctx** out_ctx) {
+    if (!out_ctx) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "out_ctx is null");
+    *out_ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(NEEDLE_HIP_ERR_NO_DEVICE, "no HIP device is visible; this library has no CPU path");
+    if (device_id < 0 || device_id >= count)
+        return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "device %d out of range (%d visible)", device_id, count);
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(NEEDLE_HIP_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device_id,
+                    prop.gcnArchName);
+    needle_hip_ctx* c = new (std::nothrow) needle_hip_ctx();
+    if (!c) return fail(NEEDLE_HIP_ERR_OUT_OF_MEMORY, "host allocation failed");
+    c->device = device_id;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
+    if (e != hipSuccess) {
+        needle_hip_shutdown(c);
+        return fail(NEEDLE_HIP_ERR_HIP, "HIP error %d (%s) creating stream/events", (int)e, hipGetErrorString(e));
+    }
+    *out_ctx = c;
+    return NEEDLE_HIP_OK;
+}
+
+extern "C" void needle_hip_shutdown(needle_hip_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& b : c->scratch) b.release();
+    for (int i = 0; i < 4; ++i)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" needle_hip_status needle_hip_set_profiling(needle_hip_ctx* c, int on) {
+    if (!c) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "ctx is null");
+    std::lock_guard<std::mutex> g(c->mu);
+    c->profiling = on != 0;
+    return NEEDLE_HIP_OK;
+}
+
+extern "C" needle_hip_status needle_hip_get_metrics(needle_hip_ctx* c, needle_hip_metrics* out) {
+    if (!c || !out) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    *out = c->m;
+    return NEEDLE_HIP_OK;
+}
+
+extern "C" needle_hip_status needle_hip_reset_metrics(needle_hip_ctx* c) {
+    if (!c) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "ctx is null");
+    std::lock_guard<std::mutex> g(c->mu);
+    c->m = needle_hip_metrics{};
+    return NEEDLE_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// flat index build
+// ---------------------------------------------------------------------------
+static void index_free(needle_hip_index* ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->ctx->device);
+    (void)hipStreamSynchronize(ix->ctx->stream);
+    if (ix->d_op_f32 && !ix->op_f32_alias) (void)hipFree(ix->d_op_f32);
+    if (ix->d_raw) (void)hipFree(ix->d_raw);
+    if (ix->d_op_bf16) (void)hipFree(ix->d_op_bf16);
+    if (ix->d_cinit) (void)hipFree(ix->d_cinit);
+    if (ix->d_norms) (void)hipFree(ix->d_norms);
+    if (ix->d_valid) (void)hipFree(ix->d_valid);
+    for (DevBuf* b : {&ix->w_qraw, &ix->w_qop, &ix->w_qn2, &ix->w_lists, &ix->w_lcnt, &ix->w_cand, &ix->w_candn,
+                      &ix->w_tau, &ix->w_flagged, &ix->w_flagcnt, &ix->w_filter, &ix->x_keys, &ix->x_u32,
+                      &ix->x_u64, &ix->x_sel})
+        b->release();
+    delete ix;
+}
+
+static bool metric_has_first_pass(int metric) { return metric <= NEEDLE_METRIC_DOT_PRODUCT; }
+
+static needle_hip_status upload_mask(needle_hip_index* ix, const uint32_t* mask_host) {
+    if (ix->d_valid) { (void)hipFree(ix->d_valid); ix->d_valid = nullptr; }
+    if (!mask_host || ix->n == 0) return NEEDLE_HIP_OK;
+    const size_t words = (ix->n + 31) / 32;
+    HIP_TRY(hipMalloc((void**)&ix->d_valid, words * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpyAsync(ix->d_valid, mask_host, words * sizeof(uint32_t), hipMemcpyHostToDevice, ix->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ix->ctx->stream));
+    return NEEDLE_HIP_OK;
+}
+
+// d_raw already holds the rows; derive everything else.
+static needle_hip_status flat_finish_build(needle_hip_index* ix) {
+    needle_hip_ctx* c = ix->ctx;
+    if (ix->n == 0) return NEEDLE_HIP_OK;
+    uint32_t* d_flag = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_flag, 2 * sizeof(uint32_t)));
+    // validate_insert_input, src/collection/validation.rs:44-52: no NaN / Inf rows
+    hipError_t e = launch_validate_rows(ix->d_raw, ix->n, ix->dim, d_flag, c->stream);
+    uint32_t bad = 0xffffffffu;
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipFree(d_flag); HIP_TRY(e); }
+    if (bad != 0xffffffffu) {
+        (void)hipFree(d_flag);
+        return fail(NEEDLE_HIP_ERR_INVALID_VECTOR, "Invalid vector: row %u contains NaN or Inf", bad);
+    }
+    if (!metric_has_first_pass(ix->metric)) { (void)hipFree(d_flag); return NEEDLE_HIP_OK; }
+
+    const bool normalize = ix->metric == NEEDLE_METRIC_COSINE;
+    ix->dpad_f32 = round_up(ix->dim, flat_scan_kstep(NEEDLE_PRECISION_FP32));
+    ix->op_f32_alias = !normalize && ix->dpad_f32 == ix->dim;
+    e = hipSuccess;
+    if (ix->op_f32_alias) {
+        ix->d_op_f32 = ix->d_raw;
+    } else {
+        const size_t bytes = (size_t)ix->n_pad * ix->dpad_f32 * sizeof(float);
+        e = hipMalloc((void**)&ix->d_op_f32, bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(ix->d_op_f32, 0, bytes, c->stream);
+    }
+    if (e == hipSuccess) e = hipMalloc((void**)&ix->d_norms, (size_t)ix->n_pad * sizeof(float));
+    if (e == hipSuccess && ix->metric == NEEDLE_METRIC_EUCLIDEAN) {
+        e = hipMalloc((void**)&ix->d_cinit, (size_t)ix->n_pad * sizeof(float));
+        if (e == hipSuccess) e = hipMemsetAsync(ix->d_cinit, 0, (size_t)ix->n_pad * sizeof(float), c->stream);
+    }
+    if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, 2 * sizeof(uint32_t), c->stream);
+    if (e == hipSuccess)
+        e = launch_row_prep(ix->d_raw, ix->n, ix->dim, ix->dpad_f32, normalize, ix->op_f32_alias ? nullptr : ix->d_op_f32,
+                            nullptr, ix->d_cinit, ix->d_norms, nullptr, d_flag, c->stream);
+    uint32_t bits = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&bits, d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_flag);
+    HIP_TRY(e);
+    memcpy(&ix->max_norm, &bits, sizeof(float));
+    return NEEDLE_HIP_OK;
+}
+
+static needle_hip_status flat_alloc(needle_hip_ctx* c, uint64_t n, uint32_t dim, needle_metric metric,
+                                    needle_arith arith, needle_hip_index** out) {
+    if (!c || !out) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (dim == 0) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "dimension must be positive");
+    if ((int)metric < 0 || (int)metric > NEEDLE_METRIC_CHEBYSHEV)
+        return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "unknown metric %d", (int)metric);
+    if (arith != NEEDLE_ARITH_DISTANCE_RS && arith != NEEDLE_ARITH_ACCEL_CHUNK4)
+        return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "unknown arithmetic %d", (int)arith);
+    if (arith == NEEDLE_ARITH_ACCEL_CHUNK4 && metric != NEEDLE_METRIC_COSINE && metric != NEEDLE_METRIC_EUCLIDEAN &&
+        metric != NEEDLE_METRIC_DOT_PRODUCT)
+        return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "the accelerator arithmetic covers cosine, euclidean and dot product only");
+    if (n >= 0xfffffff0ull - TILE_ROWS) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "at most 2^32-272 rows per index");
+    HIP_TRY(hipSetDevice(c->device));
+    needle_hip_index* ix = new (std::nothrow) needle_hip_index();
+    if (!ix) return fail(NEEDLE_HIP_ERR_OUT_OF_MEMORY, "host allocation failed");
+    ix->ctx = c;
+    ix->n = n;
+    ix->dim = dim;
+    ix->metric = metric;
+    ix->arith = arith;
+    ix->n_pad = round_up((uint32_t)n, TILE_ROWS);
+    if (n > 0) {
+        const size_t bytes = (size_t)ix->n_pad * dim * sizeof(float);
+        hipError_t e = hipMalloc((void**)&ix->d_raw, bytes);
+        if (e == hipSuccess && ix->n_pad > n)
+            e = hipMemsetAsync(ix->d_raw + (size_t)n * dim, 0, (size_t)(ix->n_pad - n) * dim * sizeof(float), c->stream);
+        if (e != hipSuccess) { index_free(ix); HIP_TRY(e); }
+    }
+    *out = ix;
+    return NEEDLE_HIP_OK;
+}
+
+extern "C" needle_hip_status needle_hip_flat_build(needle_hip_ctx* c, const float* base, uint64_t n, uint32_t dim,
+                                                   needle_metric metric, needle_arith arith,
+                                                   const uint32_t* valid_bitmask, needle_hip_index** out) {
+    if (n > 0 && !base) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "base is null");
+    needle_hip_index* ix = nullptr;
+    ST_TRY(flat_alloc(c, n, dim, metric, arith, &ix));
+    needle_hip_status st = NEEDLE_HIP_OK;
+    if (n > 0) {
+        hipError_t e = hipMemcpyAsync(ix->d_raw, base, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) st = fail(NEEDLE_HIP_ERR_HIP, "HIP error %d (%s) uploading the base", (int)e, hipGetErrorString(e));
+    }
+    if (st == NEEDLE_HIP_OK) st = flat_finish_build(ix);
+    if (st == NEEDLE_HIP_OK) st = upload_mask(ix, valid_bitmask);
+    if (st != NEEDLE_HIP_OK) { index_free(ix); *out = nullptr; return st; }
+    *out = ix;
+    return NEEDLE_HIP_OK;
+}
+
+extern "C" needle_hip_status needle_hip_flat_build_rows(needle_hip_ctx* c, const float* const* rows, uint64_t n,
+                                                        uint32_t dim, needle_metric metric, needle_arith arith,
+                                                        const uint32_t* valid_bitmask, needle_hip_index** out) {
+    if (n > 0 && !rows) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "rows is null");
+    // flatten Vec<Vec<f32>> into one staging block, then the contiguous path
+    std::vector<float> flat;
+    try {
+        flat.resize((size_t)n * dim);
+    } catch (...) {
+        return fail(NEEDLE_HIP_ERR_OUT_OF_MEMORY, "host staging allocation failed");
+    }
+    for (uint64_t i = 0; i < n; ++i) {
+        if (!rows[i]) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "row %llu is null", (unsigned long long)i);
+        memcpy(flat.data() + (size_t)i * dim, rows[i], (size_t)dim * sizeof(float));
+    }
+    return needle_hip_flat_build(c, flat.data(), n, dim, metric, arith, valid_bitmask, out);
+}
+
+extern "C" needle_hip_status needle_hip_flat_build_device(needle_hip_ctx* c, const float* d_base, uint64_t n,
+                                                          uint32_t dim, needle_metric metric, needle_arith arith,
+                                                          const uint32_t* valid_bitmask_host, needle_hip_index** out) {
+    if (n > 0 && !d_base) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "d_base is null");
+    needle_hip_index* ix = nullptr;
+    ST_TRY(flat_alloc(c, n, dim, metric, arith, &ix));
+    needle_hip_status st = NEEDLE_HIP_OK;
+    if (n > 0) {
+        hipError_t e = hipMemcpyAsync(ix->d_raw, d_base, (size_t)n * dim * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) st = fail(NEEDLE_HIP_ERR_HIP, "HIP error %d (%s) copying the base", (int)e, hipGetErrorString(e));
+    }
+    if (st == NEEDLE_HIP_OK) st = flat_finish_build(ix);
+    if (st == NEEDLE_HIP_OK) st = upload_mask(ix, valid_bitmask_host);
+    if (st != NEEDLE_HIP_OK) { index_free(ix); *out = nullptr; return st; }
+    *out = ix;
+    return NEEDLE_HIP_OK;
+}
+
+extern "C" needle_hip_status needle_hip_index_set_valid_mask(needle_hip_index* ix, const uint32_t* valid_bitmask) {
+    if (!ix) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "index is null");
+    std::lock_guard<std::mutex> g(ix->mu);
+    HIP_TRY(hipSetDevice(ix->ctx->device));
+    return upload_mask(ix, valid_bitmask);
+}
+
+extern "C" void needle_hip_index_destroy(needle_hip_index* ix) { index_free(ix); }
+extern "C" uint64_t needle_hip_index_len(const needle_hip_index* ix) { return ix ? ix->n : 0; }
+extern "C" uint32_t needle_hip_index_dimensions(const needle_hip_index* ix) { return ix ? ix->dim : 0; }
+
+// ---------------------------------------------------------------------------
+// search
+// ---------------------------------------------------------------------------
+static uint32_t choose_kprime(uint32_t k, int precision) {
+    // candidates kept per query by the first pass: k plus slack for the rows
+    // whose first-pass order differs from the reference order
+    const uint32_t slack = precision == NEEDLE_PRECISION_BF16 ? 54 : 22;
+    return round_up(k + slack, 16);
+}
+
+struct SplitPlan { uint32_t n_splits, tiles_per_split, xcd_map; };
+
+// Slices of the base per query block.  Workgroups = q_tiles * n_splits should
+// fill the chip in whole rounds; a multiple of 8 slices lets each XCD keep its
+// own slices in its L2 while its 32 CUs sweep them with different query blocks.
+static SplitPlan plan_splits(uint32_t q_tiles, uint32_t n_tiles, uint32_t slots) {
+    SplitPlan best{1, n_tiles, 0};
+    double best_score = -1.0;
+    const uint32_t s_max = std::min<uint32_t>(n_tiles, 64);
+    for (uint32_t s = 1; s <= s_max; ++s) {
+        const uint32_t tps = (n_tiles + s - 1) / s;
+        const uint32_t s_eff = (n_tiles + tps - 1) / tps;
+        if (s_eff != s) continue;
+        const uint64_t blocks = (uint64_t)s_eff * q_tiles;
+        const uint64_t rounds = (blocks + slots - 1) / slots;
+        double score = (double)blocks / (double)(rounds * slots);
+        if (tps < 8 && s > 1) score -= 0.05 * (8 - tps);  // list warm-up dominates tiny slices
+        score -= 0.001 * s;
+        const bool xcd = (s_eff % 8 == 0);
+        if (xcd) score += 0.03;
+        if (score > best_score) { best_score = score; best = SplitPlan{s_eff, tps, xcd ? 1u : 0u}; }
+    }
+    return best;
+}
+
+static needle_hip_status run_exact(needle_hip_index* ix, const float* d_queries, const uint32_t* d_qsel, uint32_t f_total,
+                                   uint32_t k, const uint32_t* d_filter, uint64_t* d_out_ids, float* d_out_dists,
+                                   uint32_t* d_out_counts) {
+    needle_hip_ctx* c = ix->ctx;
+    if (f_total == 0) return NEEDLE_HIP_OK;
+    const uint32_t n = (uint32_t)ix->n;
+    // slots per round: keep the key workspace near 512 MiB
+    uint64_t fmax = (512ull << 20) / ((uint64_t)std::max<uint32_t>(n, 1) * 8ull);
+    fmax = std::max<uint64_t>(1, std::min<uint64_t>(fmax, 4096));
+    const uint32_t F = (uint32_t)std::min<uint64_t>(fmax, f_total);
+    HIP_TRY(ix->x_keys.ensure((size_t)F * n * sizeof(uint64_t)));
+    HIP_TRY(ix->x_u32.ensure((size_t)F * (4 + 256) * sizeof(uint32_t)));
+    HIP_TRY(ix->x_u64.ensure((size_t)F * sizeof(uint64_t)));
+    HIP_TRY(ix->x_sel.ensure((size_t)F * k * sizeof(uint64_t)));
+    for (uint32_t f0 = 0; f0 < f_total; f0 += F) {
+        const uint32_t f = std::min(F, f_total - f0);
+        ExactParams p{};
+        p.base_raw = ix->d_raw;
+        p.valid = ix->d_valid;
+        p.filter = d_filter;
+        p.keys = ix->x_keys.as<uint64_t>();
+        uint32_t* u = ix->x_u32.as<uint32_t>();
+        p.live = u; p.k_eff = u + F; p.kth_rem = u + 2 * F; p.sel_n = u + 3 * F; p.hist = u + 4 * F;
+        p.prefix = ix->x_u64.as<uint64_t>();
+        p.sel = ix->x_sel.as<uint64_t>();
+        p.f = f; p.n = n; p.dim = ix->dim; p.k = k; p.metric = ix->metric; p.arith = ix->arith;
+        if (d_qsel) {  // slots name arbitrary queries of the batch
+            p.qsel = d_qsel + f0;
+            p.query_raw = d_queries;
+            p.out_ids = d_out_ids; p.out_dists = d_out_dists; p.out_counts = d_out_counts;
+        } else {       // slot s is query f0 + s
+            p.qsel = nullptr;
+            p.query_raw = d_queries + (size_t)f0 * ix->dim;
+            p.out_ids = d_out_ids + (size_t)f0 * k; p.out_dists = d_out_dists + (size_t)f0 * k;
+            p.out_counts = d_out_counts + f0;
+        }
+        HIP_TRY(launch_exact_scan(p, c->stream));
+    }
+    return NEEDLE_HIP_OK;
+}
+
+static needle_hip_status ensure_bf16_copy(needle_hip_index* ix) {
+    if (ix->d_op_bf16) return NEEDLE_HIP_OK;
+    return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "bf16 first pass is not built into this library version");
+}
+
+// Device-resident search of one batch of at most QB queries.
+static needle_hip_status search_batch_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k,
+                                             int precision, const uint32_t* d_filter, uint64_t* d_out_ids,
+                                             float* d_out_dists, uint32_t* d_out_counts) {
+    needle_hip_ctx* c = ix->ctx;
+    const uint32_t n = (uint32_t)ix->n;
+    const uint32_t kprime = choose_kprime(std::min(k, n), precision);
+    const bool exact_only = precision == NEEDLE_PRECISION_EXACT_SCAN || !metric_has_first_pass(ix->metric) ||
+                            kprime > KPRIME_MAX;
+    if (exact_only) {
+        ST_TRY(run_exact(ix, d_queries, nullptr, q, k, d_filter, d_out_ids, d_out_dists, d_out_counts));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::lock_guard<std::mutex> g(c->mu);
+        c->m.fallback_queries += q;
+        return NEEDLE_HIP_OK;
+    }
+    if (precision == NEEDLE_PRECISION_BF16) ST_TRY(ensure_bf16_copy(ix));
+
+    const uint32_t q_pad = round_up(q, TILE_QUERIES), q_tiles = q_pad / TILE_QUERIES;
+    const uint32_t n_tiles = ix->n_pad / TILE_ROWS;
+    const uint32_t dpad = precision == NEEDLE_PRECISION_BF16 ? ix->dpad_bf16 : ix->dpad_f32;
+    const uint32_t cap = list_cap(kprime);
+    const SplitPlan plan = plan_splits(q_tiles, n_tiles, (uint32_t)c->n_cu * (uint32_t)flat_scan_blocks_per_cu(precision));
+    const size_t elt = precision == NEEDLE_PRECISION_BF16 ? 2 : 4;
+
+    HIP_TRY(ix->w_qop.ensure((size_t)q_pad * dpad * elt));
+    HIP_TRY(ix->w_qn2.ensure((size_t)q_pad * sizeof(double)));
+    HIP_TRY(ix->w_lists.ensure((size_t)q_pad * plan.n_splits * cap * sizeof(uint2)));
+    HIP_TRY(ix->w_lcnt.ensure((size_t)q_pad * plan.n_splits * sizeof(uint32_t)));
+    HIP_TRY(ix->w_cand.ensure((size_t)q * kprime * sizeof(uint32_t)));
+    HIP_TRY(ix->w_candn.ensure((size_t)q * sizeof(uint32_t)));
+    HIP_TRY(ix->w_tau.ensure((size_t)q * sizeof(float)));
+    HIP_TRY(ix->w_flagged.ensure((size_t)q * sizeof(uint32_t)));
+    HIP_TRY(ix->w_flagcnt.ensure(sizeof(uint32_t)));
+
+    HIP_TRY(hipMemsetAsync(ix->w_qop.p, 0, (size_t)q_pad * dpad * elt, c->stream));
+    HIP_TRY(hipMemsetAsync(ix->w_flagcnt.p, 0, sizeof(uint32_t), c->stream));
+    const bool normalize = ix->metric == NEEDLE_METRIC_COSINE;
+    HIP_TRY(launch_row_prep(d_queries, q, ix->dim, dpad, normalize,
+                            precision == NEEDLE_PRECISION_BF16 ? nullptr : ix->w_qop.as<float>(),
+                            precision == NEEDLE_PRECISION_BF16 ? ix->w_qop.as<uint16_t>() : nullptr, nullptr, nullptr,
+                            ix->w_qn2.as<double>(), nullptr, c->stream));
+
+    ScanParams sp{};
+    sp.base_op = precision == NEEDLE_PRECISION_BF16 ? (const void*)ix->d_op_bf16 : (const void*)ix->d_op_f32;
+    sp.query_op = ix->w_qop.p;
+    sp.cinit = ix->d_cinit;
+    sp.valid = ix->d_valid;
+    sp.filter = d_filter;
+    sp.lists = ix->w_lists.as<uint2>();
+    sp.list_counts = ix->w_lcnt.as<uint32_t>();
+    sp.n = n;
+    sp.n_tiles = n_tiles;
+    sp.tiles_per_split = plan.tiles_per_split;
+    sp.n_splits = plan.n_splits;
+    sp.q_tiles = q_tiles;
+    sp.dpad = dpad;
+    sp.kprime = kprime;
+    sp.cap = cap;
+    sp.xcd_map = plan.xcd_map;
+    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(launch_flat_scan(precision, sp, c->stream));
+    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+
+    PostParams pp{};
+    pp.base_raw = ix->d_raw;
+    pp.query_raw = d_queries;
+    pp.qnorm2 = ix->w_qn2.as<double>();
+    pp.lists = sp.lists;
+    pp.list_counts = sp.list_counts;
+    pp.cand_ids = ix->w_cand.as<uint32_t>();
+    pp.cand_n = ix->w_candn.as<uint32_t>();
+    pp.tau_star = ix->w_tau.as<float>();
+    pp.flagged = ix->w_flagged.as<uint32_t>();
+    pp.flag_count = ix->w_flagcnt.as<uint32_t>();
+    pp.out_ids = d_out_ids;
+    pp.out_dists = d_out_dists;
+    pp.out_counts = d_out_counts;
+    pp.q = q; pp.n = n; pp.dim = ix->dim; pp.k = k; pp.kprime = kprime; pp.cap = cap; pp.n_splits = plan.n_splits;
+    pp.metric = ix->metric; pp.arith = ix->arith; pp.precision = precision;
+    pp.max_norm = ix->max_norm;
+    HIP_TRY(launch_merge_select(pp, c->stream));
+    HIP_TRY(launch_rescore_finalize(pp, c->stream));
+
+    uint32_t n_flagged = 0;
+    HIP_TRY(hipMemcpyAsync(&n_flagged, pp.flag_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->profiling) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        std::lock_guard<std::mutex> g(c->mu);
+        c->m.scan_launches += 1;
+        c->m.scan_ms_total += ms;
+        c->m.last_scan_ms = ms;
+    }
+    if (n_flagged > 0) {
+        if (n_flagged > q) n_flagged = q;
+        ST_TRY(run_exact(ix, d_queries, pp.flagged, n_flagged, k, d_filter, d_out_ids, d_out_dists, d_out_counts));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::lock_guard<std::mutex> g(c->mu);
+        c->m.fallback_queries += n_flagged;
+    }
+    return NEEDLE_HIP_OK;
+}
+
+static needle_hip_status search_device_locked(needle_hip_index* ix, const float* d_queries, uint32_t q,
+                                              const needle_search_params* params, const uint32_t* d_filter,
+                                              uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts) {
+    needle_hip_ctx* c = ix->ctx;
+    const uint32_t k = params->k;
+    if (k > K_MAX) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "k = %u exceeds the supported maximum %d", k, K_MAX);
+    const int precision = params->precision;
+    if (precision < NEEDLE_PRECISION_FP32 || precision > NEEDLE_PRECISION_EXACT_SCAN)
+        return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "unknown precision %d", precision);
+    if (q == 0) return NEEDLE_HIP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    if (k == 0 || ix->n == 0) {
+        // clamp_k == 0 -> vec![Vec::new(); queries.len()], src/collection/batch.rs:40-43
+        HIP_TRY(launch_fill_empty(d_out_ids, d_out_dists, d_out_counts, q, k, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    } else {
+        const uint32_t QB = 16384;
+        for (uint32_t q0 = 0; q0 < q; q0 += QB) {
+            const uint32_t qb = std::min(QB, q - q0);
+            ST_TRY(search_batch_device(ix, d_queries + (size_t)q0 * ix->dim, qb, k, precision, d_filter,
+                                       d_out_ids + (size_t)q0 * k, d_out_dists + (size_t)q0 * k, d_out_counts + q0));
+        }
+    }
+    if (c->profiling) {
+        HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+        HIP_TRY(hipEventSynchronize(c->ev[3]));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+        std::lock_guard<std::mutex> g(c->mu);
+        c->m.last_search_ms = ms;
+    }
+    std::lock_guard<std::mutex> g(c->mu);
+    c->m.searches += 1;
+    c->m.queries += q;
+    return NEEDLE_HIP_OK;
+}
+
+extern "C" needle_hip_status needle_hip_batch_search_device(needle_hip_index* ix, const float* d_queries, uint32_t q,
+                                                            const needle_search_params* params, uint64_t* d_out_ids,
+                                                            float* d_out_dists, uint32_t* d_out_counts) {
+    if (!ix || !params) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (q > 0 && (!d_queries || !d_out_counts || (params->k > 0 && (!d_out_ids || !d_out_dists))))
+        return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null query or output pointer");
+    std::lock_guard<std::mutex> g(ix->mu);
+    return search_device_locked(ix, d_queries, q, params, params->filter_bitmask, d_out_ids, d_out_dists, d_out_counts);
+}
+
+extern "C" needle_hip_status needle_hip_batch_search(needle_hip_index* ix, const float* queries, uint32_t q,
+                                                     uint32_t query_dim, const needle_search_params* params,
+                                                     uint64_t* out_ids, float* out_dists, uint32_t* out_counts) {
+    if (!ix || !params) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    // validate_query for EVERY query before any work, src/collection/batch.rs:37-39
+    if (q > 0 && query_dim != ix->dim)
+        return fail(NEEDLE_HIP_ERR_DIMENSION_MISMATCH, "Dimension mismatch: expected %u, got %u", ix->dim, query_dim);
+    if (q > 0 && (!queries || !out_counts || (params->k > 0 && (!out_ids || !out_dists))))
+        return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null query or output pointer");
+    for (uint32_t i = 0; i < q; ++i) {
+        const float* v = queries + (size_t)i * query_dim;
+        for (uint32_t j = 0; j < query_dim; ++j) {
+            if (std::isnan(v[j]))
+                return fail(NEEDLE_HIP_ERR_INVALID_VECTOR, "Invalid vector: Vector contains NaN at index %u (query %u)", j, i);
+            if (std::isinf(v[j]))
+                return fail(NEEDLE_HIP_ERR_INVALID_VECTOR, "Invalid vector: Vector contains Inf at index %u (query %u)", j, i);
+        }
+    }
+    if (q == 0) return NEEDLE_HIP_OK;
+    std::lock_guard<std::mutex> g(ix->mu);
+    needle_hip_ctx* c = ix->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t k = params->k;
+    const size_t kk = k ? k : 1;
+    HIP_TRY(ix->w_qraw.ensure((size_t)q * ix->dim * sizeof(float) + (size_t)q * kk * (sizeof(uint64_t) + sizeof(float)) +
+                              (size_t)q * sizeof(uint32_t) + 64));
+    // carve: queries | ids | dists | counts   (ids first after queries keeps 8-byte alignment)
+    unsigned char* base = ix->w_qraw.as<unsigned char>();
+    size_t off = ((size_t)q * ix->dim * sizeof(float) + 15) & ~(size_t)15;
+    float* d_q = (float*)base;
+    uint64_t* d_ids = (uint64_t*)(base + off);
+    off += (size_t)q * kk * sizeof(uint64_t);
+    float* d_d = (float*)(base + off);
+    off += (size_t)q * kk * sizeof(float);
+    uint32_t* d_c = (uint32_t*)(base + off);
+    HIP_TRY(hipMemcpyAsync(d_q, queries, (size_t)q * ix->dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const uint32_t* d_filter = nullptr;
+    if (params->filter_bitmask && ix->n > 0) {
+        const size_t words = (ix->n + 31) / 32;
+        HIP_TRY(ix->w_filter.ensure(words * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(ix->w_filter.p, params->filter_bitmask, words * sizeof(uint32_t), hipMemcpyHostToDevice,
+                               c->stream));
+        d_filter = ix->w_filter.as<uint32_t>();
+    }
+    ST_TRY(search_device_locked(ix, d_q, q, params, d_filter, d_ids, d_d, d_c));
+    if (k > 0) {
+        HIP_TRY(hipMemcpyAsync(out_ids, d_ids, (size_t)q * k * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(out_dists, d_d, (size_t)q * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(out_counts, d_c, (size_t)q * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NEEDLE_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// operator-level calls
+// ---------------------------------------------------------------------------
+extern "C" needle_hip_status needle_hip_batch_distance(needle_hip_ctx* c, needle_metric metric, needle_arith arith,
+                                                       const float* query, const float* base, uint64_t n,
+                                                       uint32_t dim, float* out) {
+    if (!c) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (metric != NEEDLE_METRIC_COSINE && metric != NEEDLE_METRIC_EUCLIDEAN && metric != NEEDLE_METRIC_DOT_PRODUCT)
+        return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "batch distance covers cosine, euclidean and dot product");
+    if (n == 0) return NEEDLE_HIP_OK;  // vectors.is_empty() -> Ok(vec![]), gpu/mod.rs:315-317
+    if (!query || !base || !out || dim == 0) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->scratch[0].ensure((size_t)dim * sizeof(float)));
+    HIP_TRY(c->scratch[1].ensure((size_t)n * dim * sizeof(float)));
+    HIP_TRY(c->scratch[2].ensure((size_t)n * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(c->scratch[0].p, query, (size_t)dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->scratch[1].p, base, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_batch_distance(c->scratch[0].as<float>(), c->scratch[1].as<float>(), n, dim, metric, arith,
+                                  c->scratch[2].as<float>(), c->stream));
+    HIP_TRY(hipMemcpyAsync(out, c->scratch[2].p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NEEDLE_HIP_OK;
+}
+
+extern "C" needle_hip_status needle_hip_kmeans_assign(needle_hip_ctx* c, needle_arith arith, const float* vectors,
+                                                      uint64_t n, const float* centroids, uint32_t n_centroids,
+                                                      uint32_t dim, uint32_t* out_assignment) {
+    if (!c) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (n == 0) return NEEDLE_HIP_OK;
+    if (!vectors || !centroids || !out_assignment || n_centroids == 0 || dim == 0)
+        return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null or empty argument");
+    if (n > 0xffffffffull) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "too many vectors");
+    // nearest centroid == 1-NN search of the centroid set, ties to the lower index
+    needle_hip_index* ix = nullptr;
+    ST_TRY(needle_hip_flat_build(c, centroids, n_centroids, dim, NEEDLE_METRIC_EUCLIDEAN, arith, nullptr, &ix));
+    needle_search_params sp{};
+    sp.k = 1;
+    sp.precision = NEEDLE_PRECISION_FP32;
+    std::vector<uint64_t> ids;
+    std::vector<float> d;
+    std::vector<uint32_t> cnt;
+    needle_hip_status st = NEEDLE_HIP_OK;
+    const uint64_t B = 1u << 18;
+    try {
+        ids.resize(std::min<uint64_t>(B, n)); d.resize(ids.size()); cnt.resize(ids.size());
+    } catch (...) {
+        needle_hip_index_destroy(ix);
+        return fail(NEEDLE_HIP_ERR_OUT_OF_MEMORY, "host allocation failed");
+    }
+    for (uint64_t i0 = 0; i0 < n && st == NEEDLE_HIP_OK; i0 += B) {
+        const uint32_t b = (uint32_t)std::min<uint64_t>(B, n - i0);
+        // rows were validated by the caller's insert path; NaN rows would be rejected here too
+        st = needle_hip_batch_search(ix, vectors + (size_t)i0 * dim, b, dim, &sp, ids.data(), d.data(), cnt.data());
+        if (st == NEEDLE_HIP_OK)
+            for (uint32_t i = 0; i < b; ++i) out_assignment[i0 + i] = cnt[i] ? (uint32_t)ids[i] : 0u;
+    }
+    needle_hip_index_destroy(ix);
+    return st;
+}
+
+extern "C" needle_hip_status needle_hip_merge_topk_device(needle_hip_ctx* c, const float* d_dists, const uint64_t* d_ids,
+                                                          const uint32_t* d_counts, uint32_t lists, uint32_t q,
+                                                          uint32_t per, uint32_t k, uint64_t* d_out_ids,
+                                                          float* d_out_dists, uint32_t* d_out_counts) {
+    if (!c) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (q == 0) return NEEDLE_HIP_OK;
+    if (!d_counts || !d_out_counts || lists == 0) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if ((uint64_t)lists * per * 16ull > 60000ull)
+        return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "merge of %u x %u entries per query exceeds the on-chip budget", lists, per);
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    if (k == 0 || per == 0) {
+        HIP_TRY(launch_fill_empty(d_out_ids, d_out_dists, d_out_counts, q, k, c->stream));
+    } else {
+        HIP_TRY(launch_merge_topk(d_dists, d_ids, d_counts, lists, q, per, k, d_out_ids, d_out_dists, d_out_counts,
+                                  c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NEEDLE_HIP_OK;
+}

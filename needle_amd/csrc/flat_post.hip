@@ -1,0 +1,404 @@
+// Everything behind the first pass: merging the per-slice candidate lists,
+// re-scoring candidates in the reference's scalar order, the error-bound check
+// that proves the candidate set sufficient, the exact scan that serves every
+// query the check rejects, the one-query distance operator and the multi-shard
+// merge.
+#include "nh_common.h"
+#include "nh_exact.h"
+#include "nh_kernels.h"
+#include "nh_select.h"
+
+namespace nh {
+
+// ---------------------------------------------------------------------------
+// merge_select: one wave per query.  Gathers the query's n_splits candidate
+// lists into LDS, keeps the kprime best by first-pass score and records the
+// score of the last one kept (tau*): every row that is NOT a candidate scored
+// <= tau* in the first pass.  Fewer than kprime entries in total means no
+// slice discarded anything: every live row is a candidate, tau* = -inf.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void merge_select_kernel(PostParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t mkeys[];
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    uint32_t total = 0;
+    for (uint32_t s = 0; s < p.n_splits; ++s) {
+        const uint32_t c = p.list_counts[(uint64_t)q * p.n_splits + s];
+        const uint2* l = p.lists + ((uint64_t)q * p.n_splits + s) * p.cap;
+        for (uint32_t i = lane; i < c; i += 64) {
+            const uint2 v = l[i];
+            mkeys[total + i] = cand_key(v.x, v.y);
+        }
+        total += c;
+    }
+    __syncthreads();
+    uint64_t prefix = 0;
+    float tau = -INFINITY;
+    if (total >= p.kprime) {
+        for (int bit = 63; bit >= 0; --bit) {
+            const uint64_t trial = prefix | (1ull << bit);
+            uint32_t cnt = 0;
+            for (uint32_t i = 0; i < total; i += 64) {
+                const bool ge = (i + lane < total) && (mkeys[i + lane] >= trial);
+                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ge));
+            }
+            if (cnt >= p.kprime) prefix = trial;
+        }
+        tau = ord2f((uint32_t)(prefix >> 32));
+    }
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint32_t base = 0;
+    for (uint32_t i = 0; i < total; i += 64) {
+        const bool keep = (i + lane < total) && (mkeys[i + lane] >= prefix);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) p.cand_ids[(uint64_t)q * p.kprime + base + __builtin_popcountll(m & lt_mask)] = ~(uint32_t)mkeys[i + lane];
+        base += __builtin_popcountll(m);
+    }
+    if (lane == 0) {
+        p.cand_n[q] = base;
+        p.tau_star[q] = tau;
+    }
+}
+
+hipError_t launch_merge_select(const PostParams& p, hipStream_t stream) {
+    if (p.q == 0) return hipSuccess;
+    const size_t lds = (size_t)p.n_splits * p.kprime * sizeof(uint64_t);
+    hipLaunchKernelGGL(merge_select_kernel, dim3(p.q), dim3(64), lds, stream, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// The bound check.  tau is the first-pass score threshold (larger = closer),
+// dk the exact distance of the k-th hit.  Returns true when no non-candidate
+// row can beat or tie the k-th hit:
+//     (lower bound on any non-candidate's reference distance)  >  dk.
+// u = 2^-24; a length-D f32 sum of products errs by at most D*u*sum|x_i y_i| in
+// any order (FMA chain, sequential, groups of four); gam doubles that and adds
+// the few extra roundings of normalisation, sqrt and divide.  A bf16 operand
+// pair adds 2^-8 relative per product.
+// ---------------------------------------------------------------------------
+__device__ inline bool bound_check(int metric, int precision, float tau, float dk, double qn2,
+                                   double bmax, uint32_t dim) {
+    if (tau == -INFINITY) return true;  // every live row was re-scored
+    if (!(dk == dk) || !(tau == tau)) return false;
+    const double u = 5.9604644775390625e-08;
+    const double gam = 2.0 * ((double)dim + 16.0) * u;
+    const double lowp = (precision == NEEDLE_PRECISION_BF16) ? (1.01 / 256.0) : 0.0;
+    const double qn = sqrt(qn2);
+    const double t = (double)tau, d = (double)dk;
+    switch (metric) {
+    case NEEDLE_METRIC_COSINE: {
+        // degenerate magnitudes: squares may underflow in the reference's f32 norms
+        if (!(qn > 1e-15) || !(qn < 1e15)) return false;
+        const double eps = lowp + 2.0 * gam /*first pass*/ + 2.0 * gam /*reference value*/;
+        return (1.0 - t - eps) > d;
+    }
+    case NEEDLE_METRIC_COSINE_NORMALIZED: {
+        const double scale = qn * bmax;
+        if (!(scale < 1e17)) return false;
+        return (1.0 - t - (lowp + 2.0 * gam) * scale) > d;
+    }
+    case NEEDLE_METRIC_DOT_PRODUCT: {
+        const double scale = qn * bmax;
+        if (!(scale < 1e17)) return false;
+        return (-t - (lowp + 2.0 * gam) * scale) > d;
+    }
+    case NEEDLE_METRIC_EUCLIDEAN: {
+        // score = q.b - |b|^2/2  ->  d^2 = |q|^2 - 2*score
+        if (!(qn < 1e17) || !(bmax < 1e17)) return false;
+        const double eps_s = (lowp + gam) * qn * bmax + gam * 0.5 * bmax * bmax;
+        const double d2 = qn2 - 2.0 * t - 2.0 * eps_s;
+        if (!(d2 > 0.0)) return false;
+        return sqrt(d2) * (1.0 - gam) > d;
+    }
+    default: return false;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// rescore_finalize: one workgroup per query, one thread per candidate.
+// Reference-order distance of every candidate, rank by (distance, id), emit the
+// k best, run the bound check on the k-th.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rescore_finalize_kernel(PostParams p) {
+    __shared__ uint64_t skey[KPRIME_MAX];
+    __shared__ float sdist[KPRIME_MAX];
+    const uint32_t q = blockIdx.x, j = threadIdx.x;
+    const uint32_t nc = p.cand_n[q];
+    const uint32_t k_eff = min(p.k, nc);
+    uint64_t key = ~0ull;
+    float d = 0.0f;
+    uint32_t id = 0;
+    if (j < nc) {
+        id = p.cand_ids[(uint64_t)q * p.kprime + j];
+        d = canon_distance(exact_distance(p.metric, p.arith, p.query_raw + (uint64_t)q * p.dim,
+                                          p.base_raw + (uint64_t)id * p.dim, p.dim));
+        key = hit_key(d, id);
+    }
+    if (j < KPRIME_MAX) { skey[j] = key; sdist[j] = d; }
+    __syncthreads();
+    if (j < nc) {
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < nc; ++i) rank += (skey[i] < key) ? 1u : 0u;
+        if (rank < k_eff) {
+            p.out_ids[(uint64_t)q * p.k + rank] = id;
+            p.out_dists[(uint64_t)q * p.k + rank] = d;
+        }
+        if (rank + 1 == k_eff) {
+            const bool ok = (nc < p.kprime) ||
+                            bound_check(p.metric, p.precision, p.tau_star[q], d, p.qnorm2[q], (double)p.max_norm, p.dim);
+            if (!ok) p.flagged[atomicAdd(p.flag_count, 1u)] = q;
+        }
+    }
+    for (uint32_t r = k_eff + j; r < p.k; r += blockDim.x) {
+        p.out_ids[(uint64_t)q * p.k + r] = ~0ull;
+        p.out_dists[(uint64_t)q * p.k + r] = INFINITY;
+    }
+    if (j == 0) p.out_counts[q] = k_eff;
+}
+
+hipError_t launch_rescore_finalize(const PostParams& p, hipStream_t stream) {
+    if (p.q == 0) return hipSuccess;
+    const uint32_t threads = ((p.kprime + 63) / 64) * 64;
+    hipLaunchKernelGGL(rescore_finalize_kernel, dim3(p.q), dim3(threads), 0, stream, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Exact scan.  keys[f][i] = (f2ord(distance) << 32 | row) for live rows, all
+// ones otherwise; the k-th smallest key is found by an 8-bit-per-pass radix
+// descent over histograms, the keys <= it are gathered and ranked.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void exact_keys_kernel(ExactParams p) {
+    const uint32_t f = blockIdx.y;
+    const uint32_t q = p.qsel ? p.qsel[f] : f;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    bool live = i < p.n;
+    if (live && p.valid) live = bit_set(p.valid, i);
+    if (live && p.filter) live = bit_set(p.filter, i);
+    uint64_t key = ~0ull;
+    if (live) {
+        const float d = canon_distance(exact_distance(p.metric, p.arith, p.query_raw + (uint64_t)q * p.dim,
+                                                      p.base_raw + (uint64_t)i * p.dim, p.dim));
+        key = hit_key(d, i);
+    }
+    if (i < p.n) p.keys[(uint64_t)f * p.n + i] = key;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(live);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&p.live[f], (uint32_t)__builtin_popcountll(m));
+}
+
+__global__ void exact_init_kernel(ExactParams p) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= p.f) return;
+    const uint32_t ke = min(p.k, p.live[f]);
+    p.k_eff[f] = ke;
+    p.kth_rem[f] = ke;
+    p.prefix[f] = 0;
+    p.sel_n[f] = 0;
+}
+
+__global__ __launch_bounds__(256) void exact_hist_kernel(ExactParams p, int shift) {
+    __shared__ uint32_t h[256];
+    const uint32_t f = blockIdx.y;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    if (p.k_eff[f] != 0) {
+        const uint64_t prefix = p.prefix[f];
+        const uint64_t* keys = p.keys + (uint64_t)f * p.n;
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < p.n; i += gridDim.x * 256) {
+            const uint64_t key = keys[i];
+            const bool match = (shift == 56) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+            if (match) atomicAdd(&h[(uint32_t)(key >> shift) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t v = h[threadIdx.x];
+    if (v) atomicAdd(&p.hist[(uint64_t)f * 256 + threadIdx.x], v);
+}
+
+__global__ void exact_pick_kernel(ExactParams p, int shift) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= p.f) return;
+    uint32_t* h = p.hist + (uint64_t)f * 256;
+    if (p.k_eff[f] != 0) {
+        uint32_t rem = p.kth_rem[f], cum = 0;
+        for (uint32_t b = 0; b < 256; ++b) {
+            const uint32_t c = h[b];
+            if (cum + c >= rem) {
+                p.prefix[f] |= (uint64_t)b << shift;
+                p.kth_rem[f] = rem - cum;
+                break;
+            }
+            cum += c;
+        }
+    }
+    for (uint32_t b = 0; b < 256; ++b) h[b] = 0;
+}
+
+__global__ __launch_bounds__(256) void exact_gather_kernel(ExactParams p) {
+    const uint32_t f = blockIdx.y;
+    if (p.k_eff[f] == 0) return;
+    const uint64_t kth = p.prefix[f];
+    const uint64_t* keys = p.keys + (uint64_t)f * p.n;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < p.n; i += gridDim.x * 256) {
+        const uint64_t key = keys[i];
+        if (key <= kth && key != ~0ull) {
+            const uint32_t slot = atomicAdd(&p.sel_n[f], 1u);
+            if (slot < p.k) p.sel[(uint64_t)f * p.k + slot] = key;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void exact_emit_kernel(ExactParams p) {
+    __shared__ uint64_t s[K_MAX];
+    const uint32_t f = blockIdx.x;
+    const uint32_t q = p.qsel ? p.qsel[f] : f;
+    const uint32_t ke = p.k_eff[f];
+    for (uint32_t i = threadIdx.x; i < ke; i += 256) s[i] = p.sel[(uint64_t)f * p.k + i];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < ke; i += 256) {
+        const uint64_t key = s[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < ke; ++j) rank += (s[j] < key) ? 1u : 0u;
+        p.out_ids[(uint64_t)q * p.k + rank] = key & 0xffffffffull;
+        p.out_dists[(uint64_t)q * p.k + rank] = ord2f((uint32_t)(key >> 32));
+    }
+    for (uint32_t r = ke + threadIdx.x; r < p.k; r += 256) {
+        p.out_ids[(uint64_t)q * p.k + r] = ~0ull;
+        p.out_dists[(uint64_t)q * p.k + r] = INFINITY;
+    }
+    if (threadIdx.x == 0) p.out_counts[q] = ke;
+}
+
+hipError_t launch_exact_scan(const ExactParams& p, hipStream_t stream) {
+    if (p.f == 0) return hipSuccess;
+    hipError_t e;
+    if ((e = hipMemsetAsync(p.live, 0, sizeof(uint32_t) * p.f, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(p.hist, 0, sizeof(uint32_t) * 256 * p.f, stream)) != hipSuccess) return e;
+    const uint32_t nb = (p.n + 255) / 256;
+    const uint32_t fb = (p.f + 63) / 64;
+    if (nb) hipLaunchKernelGGL(exact_keys_kernel, dim3(nb, p.f), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(exact_init_kernel, dim3(fb), dim3(64), 0, stream, p);
+    const uint32_t hb = nb < 1024 ? (nb ? nb : 1) : 1024;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(exact_hist_kernel, dim3(hb, p.f), dim3(256), 0, stream, p, shift);
+        hipLaunchKernelGGL(exact_pick_kernel, dim3(fb), dim3(64), 0, stream, p, shift);
+    }
+    hipLaunchKernelGGL(exact_gather_kernel, dim3(hb, p.f), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(exact_emit_kernel, dim3(p.f), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// batch_{cosine,euclidean}_distance / batch_dot_product: raw distances of one
+// query against n rows.  The dot product is reported positive.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void batch_distance_kernel(const float* __restrict__ query,
+                                                             const float* __restrict__ base, uint64_t n,
+                                                             uint32_t dim, int metric, int arith,
+                                                             float* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float d = exact_distance(metric, arith, query, base + i * dim, dim);
+    if (metric == NEEDLE_METRIC_DOT_PRODUCT) d = -d;
+    out[i] = d;
+}
+
+hipError_t launch_batch_distance(const float* d_query, const float* d_base, uint64_t n, uint32_t dim, int metric,
+                                 int arith, float* d_out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(batch_distance_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_query,
+                       d_base, n, dim, metric, arith, d_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// merge_topk: per query, `lists` sorted runs of (distance, id) -> the k best by
+// (distance, id), repeated ids dropped (the better copy stays).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict__ dists,
+                                                         const uint64_t* __restrict__ ids,
+                                                         const uint32_t* __restrict__ counts, uint32_t lists,
+                                                         uint32_t nq, uint32_t per, uint32_t k,
+                                                         uint64_t* __restrict__ out_ids,
+                                                         float* __restrict__ out_dists,
+                                                         uint32_t* __restrict__ out_counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mraw[];
+    const uint32_t cap = lists * per;
+    uint64_t* sid = (uint64_t*)mraw;
+    uint32_t* sord = (uint32_t*)(sid + cap);
+    uint32_t* sdup = sord + cap;
+    __shared__ uint32_t s_total, s_kept;
+    const uint32_t q = blockIdx.x;
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (uint32_t l = 0; l < lists; ++l) {
+            const uint32_t c = min(counts[(uint64_t)l * nq + q], per);
+            for (uint32_t j = 0; j < c; ++j) {
+                sid[t] = ids[((uint64_t)l * nq + q) * per + j];
+                sord[t] = f2ord(canon_distance(dists[((uint64_t)l * nq + q) * per + j]));
+                ++t;
+            }
+        }
+        s_total = t;
+        s_kept = 0;
+    }
+    __syncthreads();
+    const uint32_t total = s_total;
+    // entry i precedes entry j: (distance, id, position) lexicographic
+    auto before = [&](uint32_t i, uint32_t j) {
+        if (sord[i] != sord[j]) return sord[i] < sord[j];
+        if (sid[i] != sid[j]) return sid[i] < sid[j];
+        return i < j;
+    };
+    for (uint32_t j = threadIdx.x; j < total; j += 256) {
+        uint32_t dup = 0;
+        for (uint32_t i = 0; i < total; ++i) dup |= (sid[i] == sid[j] && i != j && before(i, j)) ? 1u : 0u;
+        sdup[j] = dup;
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < total; j += 256) {
+        if (sdup[j]) continue;
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < total; ++i) rank += (!sdup[i] && i != j && before(i, j)) ? 1u : 0u;
+        atomicAdd(&s_kept, 1u);
+        if (rank < k) {
+            out_ids[(uint64_t)q * k + rank] = sid[j];
+            out_dists[(uint64_t)q * k + rank] = ord2f(sord[j]);
+        }
+    }
+    __syncthreads();
+    const uint32_t kept = min(s_kept, k);
+    for (uint32_t r = kept + threadIdx.x; r < k; r += 256) {
+        out_ids[(uint64_t)q * k + r] = ~0ull;
+        out_dists[(uint64_t)q * k + r] = INFINITY;
+    }
+    if (threadIdx.x == 0) out_counts[q] = kept;
+}
+
+hipError_t launch_merge_topk(const float* d_dists, const uint64_t* d_ids, const uint32_t* d_counts, uint32_t lists,
+                             uint32_t q, uint32_t per, uint32_t k, uint64_t* d_out_ids, float* d_out_dists,
+                             uint32_t* d_out_counts, hipStream_t stream) {
+    if (q == 0) return hipSuccess;
+    const size_t lds = (size_t)lists * per * (sizeof(uint64_t) + 2 * sizeof(uint32_t));
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(q), dim3(256), lds, stream, d_dists, d_ids, d_counts, lists, q, per,
+                       k, d_out_ids, d_out_dists, d_out_counts);
+    return hipGetLastError();
+}
+
+__global__ void fill_empty_kernel(uint64_t* out_ids, float* out_dists, uint32_t* out_counts, uint32_t q,
+                                  uint32_t k) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (uint64_t)q * k) { out_ids[i] = ~0ull; out_dists[i] = INFINITY; }
+    if (i < q) out_counts[i] = 0;
+}
+
+hipError_t launch_fill_empty(uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, uint32_t q,
+                             uint32_t k, hipStream_t stream) {
+    const uint64_t total = (uint64_t)q * (k ? k : 1);
+    if (q == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_empty_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, d_out_ids,
+                       d_out_dists, d_out_counts, q, k);
+    return hipGetLastError();
+}
+
+}  // namespace nh

@@ -1,0 +1,203 @@
+// First pass of the exact flat search: scores = base x queries^T on the matrix
+// cores, with the per-query candidate selection fused behind each tile.
+//
+// One workgroup = 4 waves = a stationary block of 128 queries walking a slice of
+// the base in tiles of 128 rows.  The base rows are the MFMA A operand (rows of
+// the 32x32 result land in the accumulator registers), the queries are the B
+// operand (one query per lane), so each lane compares its 16 results per tile
+// against ITS query's running threshold with no cross-lane traffic.  A result
+// above the threshold is appended to that query's candidate list; a list that
+// grows past 2*kprime is cut back to its kprime best entries by the owning wave
+// (nh_select.h), which also raises the threshold.  Waves own disjoint queries,
+// so the selection needs no LDS, no atomics and no workgroup barrier.
+//
+// The scores are only a filter: the kept candidates are re-scored in the
+// reference's scalar order afterwards (flat_post.hip).
+#include "nh_common.h"
+#include "nh_kernels.h"
+#include "nh_select.h"
+
+namespace nh {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// accumulator register r of lane half h holds result row (r&3) + 8*(r>>2) + 4*h
+__device__ inline uint32_t row_of_reg(int r, uint32_t h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Append the passing results of one 32x32 tile (16 accumulator registers per
+// lane) and compact the lists that filled up.  `acc` rows are base rows
+// row_base + row_of_reg(r, h), the lane's query is column l31 of the wave.
+__device__ inline void push_tile(const f32x16& acc, uint32_t row_base, uint32_t h, uint32_t l31,
+                                 uint32_t lane, const ScanParams& p, uint2* __restrict__ wave_lists,
+                                 uint64_t list_stride, float& tau, uint32_t& cnt) {
+    float m = acc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+    if (__builtin_amdgcn_ballot_w64(m > tau) == 0) return;  // wave-uniform
+    uint2* mylist = wave_lists + (uint64_t)l31 * list_stride;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float key = acc[r];
+        const uint32_t row = row_base + row_of_reg(r, h);
+        bool pass = (key > tau) && (row < p.n);
+        if (pass && p.valid) pass = bit_set(p.valid, row);
+        if (pass && p.filter) pass = bit_set(p.filter, row);
+        const uint64_t pm = __builtin_amdgcn_ballot_w64(pass);
+        if (pm != 0) {
+            // lanes l31 and l31+32 serve the same query: the low half takes the
+            // first slot, the high half the next one
+            const uint32_t lo = (uint32_t)(pm >> l31) & 1u, hi = (uint32_t)(pm >> (l31 + 32)) & 1u;
+            if (pass) mylist[cnt + (h ? lo : 0u)] = make_uint2(__float_as_uint(key), row);
+            cnt += lo + hi;
+        }
+    }
+    uint64_t need = __builtin_amdgcn_ballot_w64(cnt > p.cap - 32) & 0xffffffffull;
+    while (need) {
+        const uint32_t b = (uint32_t)__builtin_ctzll(need);
+        need &= need - 1;
+        const uint32_t n_e = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)b);
+        const float t = wave_compact_list(wave_lists + (uint64_t)b * list_stride, n_e, p.kprime, lane);
+        if (l31 == b) { tau = t; cnt = p.kprime; }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fp32 operands: v_mfma_f32_32x32x2_f32, exact f32 products and accumulation
+// ---------------------------------------------------------------------------
+constexpr int F32_BK = 32;  // k-step staged per LDS buffer
+constexpr int F32_LD = 36;  // padded LDS row stride (floats): conflict-free ds_read_b128
+
+__global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
+    // [A buf0][A buf1][B buf0][B buf1], each 128 rows x 36 floats
+    __shared__ __attribute__((aligned(16))) float smem[4 * TILE_ROWS * F32_LD];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t l31 = lane & 31, h = lane >> 5;
+
+    uint32_t split, q_tile;
+    if (p.xcd_map) {
+        const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        split = xcd + 8 * (j / p.q_tiles);
+        q_tile = j % p.q_tiles;
+    } else {
+        split = blockIdx.x / p.q_tiles;
+        q_tile = blockIdx.x % p.q_tiles;
+    }
+    const uint32_t q0 = q_tile * TILE_QUERIES;
+    const uint32_t t0 = split * p.tiles_per_split;
+    const uint32_t t1 = min(t0 + p.tiles_per_split, p.n_tiles);
+
+    const uint64_t list_stride = (uint64_t)p.n_splits * p.cap;  // between consecutive queries
+    uint2* wave_lists = p.lists + ((uint64_t)(q0 + wave * 32) * p.n_splits + split) * p.cap;
+    float tau = -INFINITY;
+    uint32_t cnt = 0;
+
+    const uint32_t KC = p.dpad / F32_BK;
+    const uint32_t total = (t1 > t0 ? (t1 - t0) : 0) * KC;
+    const float* __restrict__ gA = (const float*)p.base_op;
+    const float* __restrict__ gB = (const float*)p.query_op;
+
+    f32x4 ra[4], rb[4];
+    auto load_chunk = [&](uint32_t c) {
+        const uint32_t tile = t0 + c / KC, kc = c % KC;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t idx = tid + i * 256, r = idx >> 3, c4 = idx & 7;
+            ra[i] = *(const f32x4*)(gA + (uint64_t)(tile * TILE_ROWS + r) * p.dpad + kc * F32_BK + c4 * 4);
+            rb[i] = *(const f32x4*)(gB + (uint64_t)(q0 + r) * p.dpad + kc * F32_BK + c4 * 4);
+        }
+    };
+    auto store_chunk = [&](uint32_t buf) {
+        float* As = smem + buf * (TILE_ROWS * F32_LD);
+        float* Bs = smem + (2 + buf) * (TILE_ROWS * F32_LD);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t idx = tid + i * 256, r = idx >> 3, c4 = idx & 7;
+            *(f32x4*)(As + r * F32_LD + c4 * 4) = ra[i];
+            *(f32x4*)(Bs + r * F32_LD + c4 * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[4];
+    if (total > 0) {
+        load_chunk(0);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (uint32_t c = 0; c < total; ++c) {
+        const uint32_t buf = c & 1, kc = c % KC, tile = t0 + c / KC;
+        if (c + 1 < total) load_chunk(c + 1);  // in flight behind this chunk's MFMAs
+        if (kc == 0) {
+            if (p.cinit) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[mt][r] = p.cinit[tile * TILE_ROWS + mt * 32 + row_of_reg(r, h)];
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+            }
+        }
+        const float* As = smem + buf * (TILE_ROWS * F32_LD);
+        const float* Bs = smem + (2 + buf) * (TILE_ROWS * F32_LD);
+        // lane half h takes k = 8g + 4h + j for its j-th MFMA of group g, on both
+        // operands alike, so each operand fragment is one 16-byte LDS read
+#pragma unroll
+        for (int g = 0; g < F32_BK / 8; ++g) {
+            const f32x4 b = *(const f32x4*)(Bs + (wave * 32 + l31) * F32_LD + g * 8 + h * 4);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const f32x4 a = *(const f32x4*)(As + (mt * 32 + l31) * F32_LD + g * 8 + h * 4);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc[mt], 0, 0, 0);
+            }
+        }
+        if (c + 1 < total) store_chunk(buf ^ 1);
+        __syncthreads();
+        if (kc == KC - 1) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                push_tile(acc[mt], tile * TILE_ROWS + mt * 32, h, l31, lane, p, wave_lists, list_stride, tau, cnt);
+        }
+    }
+
+    uint64_t need = __builtin_amdgcn_ballot_w64(cnt > p.kprime) & 0xffffffffull;
+    while (need) {
+        const uint32_t b = (uint32_t)__builtin_ctzll(need);
+        need &= need - 1;
+        const uint32_t n_e = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)b);
+        wave_compact_list(wave_lists + (uint64_t)b * list_stride, n_e, p.kprime, lane);
+        if (l31 == b) cnt = p.kprime;
+    }
+    if (h == 0) p.list_counts[(uint64_t)(q0 + wave * 32 + l31) * p.n_splits + split] = cnt;
+}
+
+// ---------------------------------------------------------------------------
+hipError_t launch_flat_scan(int precision, const ScanParams& p, hipStream_t stream) {
+    const uint32_t grid = p.n_splits * p.q_tiles;
+    if (grid == 0) return hipSuccess;
+    if (precision == NEEDLE_PRECISION_FP32) {
+        hipLaunchKernelGGL(flat_scan_f32_kernel, dim3(grid), dim3(256), 0, stream, p);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+int flat_scan_blocks_per_cu(int precision) {
+    int nb = 0;
+    hipError_t e = hipErrorInvalidValue;
+    if (precision == NEEDLE_PRECISION_FP32)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, flat_scan_f32_kernel, 256, 0);
+    if (e != hipSuccess || nb < 1) nb = 1;
+    return nb;
+}
+
+uint32_t flat_scan_kstep(int precision) { return precision == NEEDLE_PRECISION_FP32 ? F32_BK : 64; }
+
+}  // namespace nh

@@ -1,0 +1,79 @@
+// Shared host/device helpers for libneedle_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/needle_hip.h"
+
+namespace nh {
+
+// ---- geometry of the first-pass (MFMA) scan ------------------------------
+constexpr int TILE_ROWS = 128;     // base rows per tile (MFMA M)
+constexpr int TILE_QUERIES = 128;  // queries per workgroup (MFMA N): 4 waves x 32
+constexpr int KPRIME_MAX = 256;    // most candidates per query the first pass keeps
+constexpr int LIST_E_MAX = 9;      // ceil((2*KPRIME_MAX + 32) / 64) entries per lane
+constexpr int K_MAX = 2048;        // largest k any search accepts
+
+// Candidate list capacity per (query, split): compaction brings a list back to
+// kprime entries once it holds more than cap - 32; one MFMA tile adds at most
+// 32 rows per query between two checks.
+__host__ __device__ inline uint32_t list_cap(uint32_t kprime) { return 2 * kprime + 32; }
+
+// ---- order-preserving float <-> uint maps --------------------------------
+// f2ord is strictly increasing over all non-NaN floats (-0 < +0).
+__host__ __device__ inline uint32_t f2ord(float f) {
+#ifdef __HIP_DEVICE_COMPILE__
+    uint32_t u = __float_as_uint(f);
+#else
+    union { float f; uint32_t u; } c; c.f = f; uint32_t u = c.u;
+#endif
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float ord2f(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+#ifdef __HIP_DEVICE_COMPILE__
+    return __uint_as_float(u);
+#else
+    union { float f; uint32_t u; } c; c.u = u; return c.f;
+#endif
+}
+
+// Distances are compared as OrderedFloat does (ordered-float 4.6: NaN greatest,
+// -0 == +0): fold -0 into +0 and every NaN into the positive quiet NaN, whose
+// f2ord image is above +inf.
+__device__ inline float canon_distance(float d) {
+    if (d != d) return __uint_as_float(0x7fc00000u);
+    return d + 0.0f;
+}
+
+// Ascending key of a (distance, id) hit: smaller key = better hit, ties on the
+// distance go to the lower id.
+__device__ inline uint64_t hit_key(float canon_d, uint32_t id) {
+    return ((uint64_t)f2ord(canon_d) << 32) | (uint64_t)id;
+}
+
+__device__ inline bool bit_set(const uint32_t* __restrict__ mask, uint32_t i) {
+    return (mask[i >> 5] >> (i & 31)) & 1u;
+}
+
+// ---- launch parameters of the first-pass scan ----------------------------
+struct ScanParams {
+    const void* base_op;      // [n_pad][dpad] operand copy (f32 or bf16), zero padded
+    const void* query_op;     // [q_pad][dpad] operand copy of the queries
+    const float* cinit;       // [n_pad] accumulator seed per row (-|b|^2/2 for L2) or null
+    const uint32_t* valid;    // live-row bitmask or null
+    const uint32_t* filter;   // pre-filter bitmask or null
+    uint2* lists;             // [q_pad][n_splits][cap] (score bits, row id)
+    uint32_t* list_counts;    // [q_pad][n_splits]
+    uint32_t n;               // real rows
+    uint32_t n_tiles;         // ceil(n / TILE_ROWS)
+    uint32_t tiles_per_split;
+    uint32_t n_splits;
+    uint32_t q_tiles;         // q_pad / TILE_QUERIES
+    uint32_t dpad;            // padded dimension, multiple of the k-step
+    uint32_t kprime;
+    uint32_t cap;
+    uint32_t xcd_map;         // 1: n_splits % 8 == 0, splits pinned to blockIdx % 8
+};
+
+}  // namespace nh

@@ -1,0 +1,124 @@
+// Exact (reference-order) scalar distances on the device.
+//
+// These reproduce the reference's default-build arithmetic bit for bit: one
+// rounding per multiply and per add (the translation units are compiled with
+// -ffp-contract=off), IEEE-correct sqrt and divide
+// (-fhip-fp32-correctly-rounded-divide-sqrt), subnormals kept.
+#pragma once
+#include "nh_common.h"
+
+#pragma clang fp contract(off)
+
+namespace nh {
+
+// ---- src/distance.rs:153-316 (sequential sums folded from -0.0) ----------
+__device__ inline float exact_rs(int metric, const float* __restrict__ q,
+                                 const float* __restrict__ b, uint32_t dim) {
+    switch (metric) {
+    case NEEDLE_METRIC_COSINE: {  // distance.rs:153-164
+        float dot = -0.0f, qa = -0.0f, bb = -0.0f;
+        for (uint32_t i = 0; i < dim; ++i) {
+            float x = q[i], y = b[i];
+            float p = x * y; dot = dot + p;
+            float pq = x * x; qa = qa + pq;
+            float pb = y * y; bb = bb + pb;
+        }
+        float na = sqrtf(qa), nb = sqrtf(bb);
+        if (na == 0.0f || nb == 0.0f) return 1.0f;
+        float den = na * nb;
+        return 1.0f - (dot / den);
+    }
+    case NEEDLE_METRIC_COSINE_NORMALIZED: {  // distance.rs:193-196
+        float dot = -0.0f;
+        for (uint32_t i = 0; i < dim; ++i) { float p = q[i] * b[i]; dot = dot + p; }
+        return 1.0f - dot;
+    }
+    case NEEDLE_METRIC_EUCLIDEAN: {  // distance.rs:203-205, 249-257
+        float s = -0.0f;
+        for (uint32_t i = 0; i < dim; ++i) { float d = q[i] - b[i]; float p = d * d; s = s + p; }
+        return sqrtf(s);
+    }
+    case NEEDLE_METRIC_DOT_PRODUCT: {  // distance.rs:264-266
+        float dot = -0.0f;
+        for (uint32_t i = 0; i < dim; ++i) { float p = q[i] * b[i]; dot = dot + p; }
+        return -dot;
+    }
+    case NEEDLE_METRIC_MANHATTAN: {  // distance.rs:360-362
+        float s = -0.0f;
+        for (uint32_t i = 0; i < dim; ++i) s = s + fabsf(q[i] - b[i]);
+        return s;
+    }
+    case NEEDLE_METRIC_HAMMING: {  // distance.rs:387-395
+        uint32_t c = 0;
+        for (uint32_t i = 0; i < dim; ++i) c += ((q[i] != 0.0f) != (b[i] != 0.0f)) ? 1u : 0u;
+        return (float)c;
+    }
+    default: {  // Chebyshev, distance.rs:415-423: fold(0.0, f32::max), max drops NaN
+        float m = 0.0f;
+        for (uint32_t i = 0; i < dim; ++i) {
+            float d = fabsf(q[i] - b[i]);
+            m = (d != d) ? m : ((m != m) ? d : (d > m ? d : m));
+        }
+        return m;
+    }
+    }
+}
+
+// ---- src/experimental/gpu/common.rs:515-581 (groups of four) -------------
+__device__ inline float dot_chunk4(const float* __restrict__ a, const float* __restrict__ b,
+                                   uint32_t dim) {
+    uint32_t chunks = dim / 4;
+    float sum = 0.0f;
+    for (uint32_t c = 0; c < chunks; ++c) {
+        uint32_t o = c * 4;
+        float p0 = a[o] * b[o], p1 = a[o + 1] * b[o + 1];
+        float p2 = a[o + 2] * b[o + 2], p3 = a[o + 3] * b[o + 3];
+        float g = ((p0 + p1) + p2) + p3;
+        sum = sum + g;
+    }
+    for (uint32_t i = chunks * 4; i < dim; ++i) { float p = a[i] * b[i]; sum = sum + p; }
+    return sum;
+}
+
+__device__ inline float euclidean_chunk4(const float* __restrict__ a, const float* __restrict__ b,
+                                         uint32_t dim) {
+    uint32_t chunks = dim / 4;
+    float sum = 0.0f;
+    for (uint32_t c = 0; c < chunks; ++c) {
+        uint32_t o = c * 4;
+        float d0 = a[o] - b[o], d1 = a[o + 1] - b[o + 1];
+        float d2 = a[o + 2] - b[o + 2], d3 = a[o + 3] - b[o + 3];
+        float s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2, s3 = d3 * d3;
+        float g = ((s0 + s1) + s2) + s3;
+        sum = sum + g;
+    }
+    for (uint32_t i = chunks * 4; i < dim; ++i) { float d = a[i] - b[i]; float p = d * d; sum = sum + p; }
+    return sqrtf(sum);
+}
+
+// fused_search's distances, gpu/mod.rs:717-762: cosine with the query norm
+// precomputed (zero query norm -> 1.0 for every row), Euclidean, negated dot.
+__device__ inline float exact_chunk4(int metric, const float* __restrict__ q,
+                                     const float* __restrict__ b, uint32_t dim) {
+    switch (metric) {
+    case NEEDLE_METRIC_COSINE: {
+        float qn = sqrtf(dot_chunk4(q, q, dim));
+        if (qn == 0.0f) return 1.0f;
+        float dot = dot_chunk4(q, b, dim);
+        float nb = sqrtf(dot_chunk4(b, b, dim));
+        if (nb == 0.0f) return 1.0f;
+        float den = qn * nb;
+        return 1.0f - (dot / den);
+    }
+    case NEEDLE_METRIC_EUCLIDEAN: return euclidean_chunk4(q, b, dim);
+    default: return -dot_chunk4(q, b, dim);  // DotProduct
+    }
+}
+
+__device__ inline float exact_distance(int metric, int arith, const float* __restrict__ q,
+                                       const float* __restrict__ b, uint32_t dim) {
+    return arith == NEEDLE_ARITH_ACCEL_CHUNK4 ? exact_chunk4(metric, q, b, dim)
+                                              : exact_rs(metric, q, b, dim);
+}
+
+}  // namespace nh

@@ -1,0 +1,83 @@
+// Host-side launchers of the device kernels (internal to libneedle_hip).
+#pragma once
+#include "nh_common.h"
+
+namespace nh {
+
+// ---- flat_scan.hip ---------------------------------------------------------
+hipError_t launch_flat_scan(int precision, const ScanParams& p, hipStream_t stream);
+int flat_scan_blocks_per_cu(int precision);
+uint32_t flat_scan_kstep(int precision);
+
+// ---- prep.hip --------------------------------------------------------------
+// Per row: |b|, |b|^2 (wave-parallel sums; used by the first pass and its error
+// bound only), the operand copies of the first pass (unit-normalised when
+// `normalize`), the accumulator seed -|b|^2/2 when `want_cinit`, and the running
+// maximum norm (as float bits, rows are non-negative).
+hipError_t launch_row_prep(const float* d_rows, uint64_t n, uint32_t dim, uint32_t dpad,
+                           bool normalize, float* d_op_f32, uint16_t* d_op_bf16, float* d_cinit,
+                           float* d_norms, double* d_norm2, uint32_t* d_max_norm_bits,
+                           hipStream_t stream);
+// 0 if every value is finite, else 1 + index of the first row holding a NaN / Inf.
+hipError_t launch_validate_rows(const float* d_rows, uint64_t n, uint32_t dim, uint32_t* d_bad_row_plus1,
+                                hipStream_t stream);
+
+// ---- flat_post.hip ---------------------------------------------------------
+struct PostParams {
+    const float* base_raw;    // [n][dim] original rows
+    const float* query_raw;   // [q][dim] original queries
+    const double* qnorm2;     // [q] |q|^2
+    const uint2* lists;
+    const uint32_t* list_counts;
+    uint32_t* cand_ids;       // [q][kprime]
+    uint32_t* cand_n;         // [q]
+    float* tau_star;          // [q]
+    uint32_t* flagged;        // [q] query indices failing the bound check
+    uint32_t* flag_count;     // [1]
+    uint64_t* out_ids;        // [q][k]
+    float* out_dists;         // [q][k]
+    uint32_t* out_counts;     // [q]
+    uint32_t q, n, dim, k, kprime, cap, n_splits;
+    int metric, arith, precision;
+    float max_norm;
+};
+hipError_t launch_merge_select(const PostParams& p, hipStream_t stream);
+hipError_t launch_rescore_finalize(const PostParams& p, hipStream_t stream);
+
+// Exact scan (every row scored in the reference's scalar order): the path for
+// queries whose first-pass candidates fail the bound check, for the metrics with
+// no contraction form, and for NEEDLE_PRECISION_EXACT_SCAN.
+struct ExactParams {
+    const float* base_raw;
+    const float* query_raw;
+    const uint32_t* qsel;     // [f] query index of each slot, or null (slot == query)
+    const uint32_t* valid;
+    const uint32_t* filter;
+    uint64_t* keys;           // [f][n] workspace
+    uint32_t* live;           // [f]
+    uint32_t* k_eff;          // [f]
+    uint32_t* kth_rem;        // [f]
+    uint64_t* prefix;         // [f]
+    uint32_t* hist;           // [f][256]
+    uint64_t* sel;            // [f][k]
+    uint32_t* sel_n;          // [f]
+    uint64_t* out_ids;
+    float* out_dists;
+    uint32_t* out_counts;
+    uint32_t f, n, dim, k;
+    int metric, arith;
+};
+hipError_t launch_exact_scan(const ExactParams& p, hipStream_t stream);
+
+// One query against n rows, raw distances (dot product positive).
+hipError_t launch_batch_distance(const float* d_query, const float* d_base, uint64_t n, uint32_t dim,
+                                 int metric, int arith, float* d_out, hipStream_t stream);
+
+hipError_t launch_merge_topk(const float* d_dists, const uint64_t* d_ids, const uint32_t* d_counts,
+                             uint32_t lists, uint32_t q, uint32_t per, uint32_t k, uint64_t* d_out_ids,
+                             float* d_out_dists, uint32_t* d_out_counts, hipStream_t stream);
+
+hipError_t launch_fill_empty(uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, uint32_t q,
+                             uint32_t k, hipStream_t stream);
+
+}  // namespace nh

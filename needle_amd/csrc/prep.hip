@@ -1,0 +1,80 @@
+// Index-build / query-upload kernels: norms and the operand copies the first
+// pass multiplies.  None of these values reaches a reported distance: reported
+// distances are recomputed from the raw rows in the reference's order.
+#include "nh_common.h"
+#include "nh_kernels.h"
+
+namespace nh {
+
+__device__ inline uint16_t bf16_rne(float v) {
+    uint32_t u = __float_as_uint(v);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);  // inputs are finite
+}
+
+// one wave per row, coalesced
+__global__ __launch_bounds__(256) void row_prep_kernel(const float* __restrict__ rows, uint64_t n,
+                                                       uint32_t dim, uint32_t dpad, int normalize,
+                                                       float* __restrict__ op_f32,
+                                                       uint16_t* __restrict__ op_bf16,
+                                                       float* __restrict__ cinit,
+                                                       float* __restrict__ norms,
+                                                       double* __restrict__ norm2,
+                                                       uint32_t* __restrict__ max_norm_bits) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t row = (uint64_t)blockIdx.x * 4 + wave;
+    if (row >= n) return;
+    const float* src = rows + row * dim;
+    double s = 0.0;
+    for (uint32_t i = lane; i < dim; i += 64) { double x = (double)src[i]; s += x * x; }
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+    const float norm = (float)sqrt(s);
+    float inv = 1.0f;
+    if (normalize) inv = (s > 0.0) ? (float)(1.0 / sqrt(s)) : 0.0f;
+    for (uint32_t i = lane; i < dim; i += 64) {
+        const float v = src[i] * inv;
+        if (op_f32) op_f32[row * dpad + i] = v;
+        if (op_bf16) op_bf16[row * dpad + i] = bf16_rne(v);
+    }
+    if (lane == 0) {
+        if (norms) norms[row] = norm;
+        if (norm2) norm2[row] = s;
+        if (cinit) cinit[row] = -(float)(0.5 * s);
+        if (max_norm_bits) {
+            // round up so the stored maximum is never below a true norm
+            const float up = __uint_as_float(__float_as_uint(norm) + 1u);
+            atomicMax(max_norm_bits, __float_as_uint(up));
+        }
+    }
+}
+
+hipError_t launch_row_prep(const float* d_rows, uint64_t n, uint32_t dim, uint32_t dpad, bool normalize,
+                           float* d_op_f32, uint16_t* d_op_bf16, float* d_cinit, float* d_norms,
+                           double* d_norm2, uint32_t* d_max_norm_bits, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint32_t grid = (uint32_t)((n + 3) / 4);
+    hipLaunchKernelGGL(row_prep_kernel, dim3(grid), dim3(256), 0, stream, d_rows, n, dim, dpad,
+                       normalize ? 1 : 0, d_op_f32, d_op_bf16, d_cinit, d_norms, d_norm2, d_max_norm_bits);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void validate_rows_kernel(const float* __restrict__ rows, uint64_t total,
+                                                            uint32_t dim, uint32_t* __restrict__ bad) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const float v = rows[i];
+        if (!(fabsf(v) <= 3.40282347e+38f)) atomicMin(bad, (uint32_t)(i / dim));
+    }
+}
+
+hipError_t launch_validate_rows(const float* d_rows, uint64_t n, uint32_t dim, uint32_t* d_bad_row,
+                                hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(d_bad_row, 0xff, sizeof(uint32_t), stream);
+    if (e != hipSuccess || n == 0) return e;
+    const uint64_t total = n * dim;
+    const uint32_t grid = (uint32_t)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(validate_rows_kernel, dim3(grid), dim3(256), 0, stream, d_rows, total, dim, d_bad_row);
+    return hipGetLastError();
+}
+
+}  // namespace nh

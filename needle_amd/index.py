@@ -1,0 +1,196 @@
+"""Thin object layer over the C ABI: a device context and a resident flat index.
+
+Host arrays are numpy; device arrays are anything exposing ``data_ptr()`` (torch
+tensors).  PyTorch is plumbing here (device memory and streams for callers that
+already hold their data on the GPU); all compute is inside libneedle_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .distance import DistanceFunction
+
+PRECISION = {"fp32": _lib.PRECISION_FP32, "bf16": _lib.PRECISION_BF16, "exact": _lib.PRECISION_EXACT_SCAN}
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def pack_bitmask(bits) -> np.ndarray:
+    """bool[n] -> uint32[ceil(n/32)]; bit i lives in word i>>5 at position i&31."""
+    b = np.asarray(bits, dtype=np.bool_).reshape(-1)
+    pad = (-b.size) % 32
+    if pad:
+        b = np.concatenate([b, np.zeros(pad, dtype=np.bool_)])
+    return np.packbits(b.reshape(-1, 32), axis=1, bitorder="little").view(np.uint32).reshape(-1).copy()
+
+
+def _mask_words(mask, n):
+    if mask is None:
+        return None
+    m = np.asarray(mask)
+    if m.dtype == np.bool_:
+        if m.size != n:
+            raise ValueError(f"mask has {m.size} entries for {n} rows")
+        m = pack_bitmask(m)
+    m = np.ascontiguousarray(m, dtype=np.uint32)
+    if m.size < (n + 31) // 32:
+        raise ValueError("bitmask too short")
+    return m
+
+
+class Context:
+    """One HIP device (needle_hip_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().needle_hip_init(device, C.byref(self._h)))
+        self.device = device
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            _lib.lib().needle_hip_shutdown(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_profiling(self, on: bool) -> None:
+        _lib.check(_lib.lib().needle_hip_set_profiling(self._h, int(on)))
+
+    def metrics(self) -> dict:
+        m = _lib.Metrics()
+        _lib.check(_lib.lib().needle_hip_get_metrics(self._h, C.byref(m)))
+        return {name: getattr(m, name) for name, _ in _lib.Metrics._fields_}
+
+    def reset_metrics(self) -> None:
+        _lib.check(_lib.lib().needle_hip_reset_metrics(self._h))
+
+    # ---- operator-level calls ------------------------------------------
+    def batch_distance(self, metric: DistanceFunction, query, base, arith: int = _lib.ARITH_ACCEL_CHUNK4) -> np.ndarray:
+        q, b = _f32(query), _f32(base)
+        if b.size == 0:
+            return np.empty(0, dtype=np.float32)
+        if b.ndim != 2 or b.shape[1] != q.size:
+            raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH, "Dimension mismatch")
+        out = np.empty(b.shape[0], dtype=np.float32)
+        _lib.check(_lib.lib().needle_hip_batch_distance(self._h, int(metric), arith, q.ctypes.data, b.ctypes.data,
+                                                        b.shape[0], q.size, out.ctypes.data))
+        return out
+
+    def kmeans_assign(self, vectors, centroids, arith: int = _lib.ARITH_ACCEL_CHUNK4) -> np.ndarray:
+        v, c = _f32(vectors), _f32(centroids)
+        out = np.zeros(v.shape[0], dtype=np.uint32)
+        if v.shape[0]:
+            _lib.check(_lib.lib().needle_hip_kmeans_assign(self._h, arith, v.ctypes.data, v.shape[0], c.ctypes.data,
+                                                           c.shape[0], v.shape[1], out.ctypes.data))
+        return out
+
+    def merge_topk_device(self, d_dists, d_ids, d_counts, lists: int, q: int, per: int, k: int, d_out_ids, d_out_dists,
+                          d_out_counts) -> None:
+        _lib.check(_lib.lib().needle_hip_merge_topk_device(self._h, d_dists.data_ptr(), d_ids.data_ptr(),
+                                                           d_counts.data_ptr(), lists, q, per, k, d_out_ids.data_ptr(),
+                                                           d_out_dists.data_ptr(), d_out_counts.data_ptr()))
+
+
+class FlatIndex:
+    """Resident exact flat index (needle_hip_index, kind flat)."""
+
+    def __init__(self, ctx: Context, base, metric: DistanceFunction, *, arith: int = _lib.ARITH_DISTANCE_RS,
+                 valid=None, dim: int | None = None):
+        self.ctx = ctx
+        self.metric = DistanceFunction(metric)
+        self._h = C.c_void_p()
+        L = _lib.lib()
+        if hasattr(base, "data_ptr"):  # device tensor
+            if base.dim() != 2 or str(base.dtype) != "torch.float32" or not base.is_contiguous():
+                raise ValueError("device base must be a contiguous float32 [n, dim] tensor")
+            n, d = int(base.shape[0]), int(base.shape[1])
+            vm = _mask_words(valid, n)
+            _lib.check(L.needle_hip_flat_build_device(ctx._h, base.data_ptr(), n, d, int(self.metric), arith,
+                                                      vm.ctypes.data if vm is not None else None, C.byref(self._h)))
+        else:
+            b = _f32(base)
+            if b.ndim != 2:
+                if dim is None:
+                    raise ValueError("an empty base needs an explicit dim")
+                b = b.reshape(0, dim)
+            n, d = b.shape
+            if n == 0 and dim is not None:
+                d = dim
+            vm = _mask_words(valid, n)
+            _lib.check(L.needle_hip_flat_build(ctx._h, b.ctypes.data if n else None, n, d, int(self.metric), arith,
+                                               vm.ctypes.data if vm is not None else None, C.byref(self._h)))
+        self.n, self.dim = n, d
+
+    @classmethod
+    def from_rows(cls, ctx: Context, rows, metric: DistanceFunction, *, arith: int = _lib.ARITH_DISTANCE_RS, valid=None):
+        """Build from separately allocated rows (the reference's Vec<Vec<f32>>)."""
+        keep = [_f32(r) for r in rows]
+        n = len(keep)
+        d = keep[0].size if n else 0
+        ptrs = (C.c_void_p * max(n, 1))(*[r.ctypes.data for r in keep])
+        self = cls.__new__(cls)
+        self.ctx, self.metric, self._h = ctx, DistanceFunction(metric), C.c_void_p()
+        vm = _mask_words(valid, n)
+        _lib.check(_lib.lib().needle_hip_flat_build_rows(ctx._h, ptrs, n, d, int(metric), arith,
+                                                         vm.ctypes.data if vm is not None else None, C.byref(self._h)))
+        self.n, self.dim = n, d
+        return self
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            _lib.lib().needle_hip_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return int(_lib.lib().needle_hip_index_len(self._h))
+
+    def set_valid_mask(self, valid) -> None:
+        vm = _mask_words(valid, self.n)
+        _lib.check(_lib.lib().needle_hip_index_set_valid_mask(self._h, vm.ctypes.data if vm is not None else None))
+
+    def search(self, queries, k: int, *, precision: str = "fp32", filter_mask=None):
+        """Host arrays in, host arrays out: (ids[q,k] uint64, dists[q,k] float32, counts[q] uint32)."""
+        q = _f32(queries)
+        if q.ndim == 1:
+            q = q.reshape(1, -1)
+        if q.ndim != 2:
+            raise ValueError("queries must be [q, dim]")
+        nq, qd = q.shape
+        kk = max(k, 1)
+        ids = np.full((nq, kk), np.iinfo(np.uint64).max, dtype=np.uint64)
+        dists = np.full((nq, kk), np.inf, dtype=np.float32)
+        counts = np.zeros(nq, dtype=np.uint32)
+        fm = _mask_words(filter_mask, self.n)
+        sp = _lib.SearchParams(k=k, nprobe=0, precision=PRECISION[precision], reserved=0,
+                               filter_bitmask=fm.ctypes.data if fm is not None else None)
+        _lib.check(_lib.lib().needle_hip_batch_search(self._h, q.ctypes.data if nq else None, nq, qd, C.byref(sp),
+                                                      ids.ctypes.data, dists.ctypes.data, counts.ctypes.data))
+        return ids[:, :k], dists[:, :k], counts
+
+    def search_device(self, d_queries, k: int, d_out_ids, d_out_dists, d_out_counts, *, precision: str = "fp32",
+                      d_filter=None) -> None:
+        """Device tensors in and out (float32 [q,dim]; int64/uint64 [q,k]; float32 [q,k]; int32/uint32 [q])."""
+        nq = int(d_queries.shape[0])
+        if int(d_queries.shape[1]) != self.dim:
+            raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                         f"Dimension mismatch: expected {self.dim}, got {int(d_queries.shape[1])}")
+        sp = _lib.SearchParams(k=k, nprobe=0, precision=PRECISION[precision], reserved=0,
+                               filter_bitmask=d_filter.data_ptr() if d_filter is not None else None)
+        _lib.check(_lib.lib().needle_hip_batch_search_device(self._h, d_queries.data_ptr(), nq, C.byref(sp),
+                                                             d_out_ids.data_ptr(), d_out_dists.data_ptr(),
+                                                             d_out_counts.data_ptr()))
