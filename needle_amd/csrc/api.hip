@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -97,7 +98,7 @@ struct needle_hip_index {
     float min_pos_norm = 0.0f;
     std::mutex mu;
     // per-search workspace (grow-only)
-    DevBuf w_qraw, w_qop, w_qn2, w_lists, w_lcnt, w_cand, w_candn, w_tau, w_flagged, w_flagcnt, w_filter;
+    DevBuf w_qraw, w_qop, w_qn2, w_lists, w_lcnt, w_cand, w_candn, w_tau, w_flagged, w_flagcnt, w_filter, w_premax, w_tau0;
     DevBuf x_keys, x_u32, x_u64, x_sel;
 };
 
@@ -203,7 +204,7 @@ static void index_free(needle_hip_index* ix) {
     if (ix->d_norms) (void)hipFree(ix->d_norms);
     if (ix->d_valid) (void)hipFree(ix->d_valid);
     for (DevBuf* b : {&ix->w_qraw, &ix->w_qop, &ix->w_qn2, &ix->w_lists, &ix->w_lcnt, &ix->w_cand, &ix->w_candn,
-                      &ix->w_tau, &ix->w_flagged, &ix->w_flagcnt, &ix->w_filter, &ix->x_keys, &ix->x_u32,
+                      &ix->w_tau, &ix->w_flagged, &ix->w_flagcnt, &ix->w_filter, &ix->w_premax, &ix->w_tau0, &ix->x_keys, &ix->x_u32,
                       &ix->x_u64, &ix->x_sel})
         b->release();
     delete ix;
@@ -471,7 +472,15 @@ static needle_hip_status search_batch_device(needle_hip_index* ix, const float* 
     const uint32_t n_tiles = ix->n_pad / TILE_ROWS;
     const uint32_t dpad = precision == NEEDLE_PRECISION_BF16 ? ix->dpad_bf16 : ix->dpad_f32;
     const uint32_t cap = list_cap(kprime);
-    const SplitPlan plan = plan_splits(q_tiles, n_tiles, (uint32_t)c->n_cu * (uint32_t)flat_scan_blocks_per_cu(precision));
+    SplitPlan plan = plan_splits(q_tiles, n_tiles, (uint32_t)c->n_cu * (uint32_t)flat_scan_blocks_per_cu(precision));
+    if (const char* ds = getenv("NEEDLE_HIP_DEBUG_SPLITS")) {  // development override, applied before any sizing
+        const uint32_t s = (uint32_t)atoi(ds);
+        if (s >= 1 && s <= n_tiles && s <= 64) {
+            plan.tiles_per_split = (n_tiles + s - 1) / s;
+            plan.n_splits = (n_tiles + plan.tiles_per_split - 1) / plan.tiles_per_split;
+            plan.xcd_map = (plan.n_splits % 8 == 0) ? 1u : 0u;
+        }
+    }
     const size_t elt = precision == NEEDLE_PRECISION_BF16 ? 2 : 4;
 
     HIP_TRY(ix->w_qop.ensure((size_t)q_pad * dpad * elt));
@@ -509,7 +518,19 @@ static needle_hip_status search_batch_device(needle_hip_index* ix, const float* 
     sp.kprime = kprime;
     sp.cap = cap;
     sp.xcd_map = plan.xcd_map;
+    if (const char* dbg = getenv("NEEDLE_HIP_DEBUG")) sp.debug = (uint32_t)atoi(dbg);
+    // threshold seeding: worth it once a slice is much longer than the sample
+    const uint32_t pre_tiles = std::min<uint32_t>(8, plan.tiles_per_split / 8);
+    const bool seeded = pre_tiles >= 1 && !(sp.debug & 2u);
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    if (seeded) {
+        HIP_TRY(ix->w_premax.ensure((size_t)q_pad * 8 * plan.n_splits * sizeof(float)));
+        HIP_TRY(ix->w_tau0.ensure((size_t)q_pad * sizeof(float)));
+        sp.pre_max = ix->w_premax.as<float>();
+        sp.pre_tiles = pre_tiles;
+        HIP_TRY(launch_flat_prepass(precision, sp, ix->w_tau0.as<float>(), c->stream));
+        sp.tau0 = ix->w_tau0.as<float>();
+    }
     HIP_TRY(launch_flat_scan(precision, sp, c->stream));
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
 
@@ -522,6 +543,7 @@ static needle_hip_status search_batch_device(needle_hip_index* ix, const float* 
     pp.cand_ids = ix->w_cand.as<uint32_t>();
     pp.cand_n = ix->w_candn.as<uint32_t>();
     pp.tau_star = ix->w_tau.as<float>();
+    pp.tau0 = sp.tau0;
     pp.flagged = ix->w_flagged.as<uint32_t>();
     pp.flag_count = ix->w_flagcnt.as<uint32_t>();
     pp.out_ids = d_out_ids;

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(64) void merge_select_kernel(PostParams p) {
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
     uint32_t total = 0;
     for (uint32_t s = 0; s < p.n_splits; ++s) {
-        const uint32_t c = p.list_counts[(uint64_t)q * p.n_splits + s];
+        const uint32_t c = min(p.list_counts[(uint64_t)q * p.n_splits + s], p.kprime);  // a slice keeps <= kprime
         const uint2* l = p.lists + ((uint64_t)q * p.n_splits + s) * p.cap;
         for (uint32_t i = lane; i < c; i += 64) {
             const uint2 v = l[i];
@@ -54,6 +54,8 @@ __global__ __launch_bounds__(64) void merge_select_kernel(PostParams p) {
         base += __builtin_popcountll(m);
     }
     if (lane == 0) {
+        // rows the main pass never listed scored <= its starting threshold
+        if (p.tau0) tau = fmaxf(tau, p.tau0[q]);
         p.cand_n[q] = base;
         p.tau_star[q] = tau;
     }
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void rescore_finalize_kernel(PostParams p) {
     __shared__ uint64_t skey[KPRIME_MAX];
     __shared__ float sdist[KPRIME_MAX];
     const uint32_t q = blockIdx.x, j = threadIdx.x;
-    const uint32_t nc = p.cand_n[q];
+    const uint32_t nc = min(p.cand_n[q], p.kprime);
     const uint32_t k_eff = min(p.k, nc);
     uint64_t key = ~0ull;
     float d = 0.0f;
@@ -144,8 +146,7 @@ __global__ __launch_bounds__(256) void rescore_finalize_kernel(PostParams p) {
             p.out_dists[(uint64_t)q * p.k + rank] = d;
         }
         if (rank + 1 == k_eff) {
-            const bool ok = (nc < p.kprime) ||
-                            bound_check(p.metric, p.precision, p.tau_star[q], d, p.qnorm2[q], (double)p.max_norm, p.dim);
+            const bool ok = bound_check(p.metric, p.precision, p.tau_star[q], d, p.qnorm2[q], (double)p.max_norm, p.dim);
             if (!ok) p.flagged[atomicAdd(p.flag_count, 1u)] = q;
         }
     }

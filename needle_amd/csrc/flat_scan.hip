@@ -68,6 +68,8 @@ __device__ inline void push_tile(const f32x16& acc, uint32_t row_base, uint32_t 
 constexpr int F32_BK = 32;  // k-step staged per LDS buffer
 constexpr int F32_LD = 36;  // padded LDS row stride (floats): conflict-free ds_read_b128
 
+// PRE = true: threshold-seeding pre-pass (group maxima only, no candidate lists).
+template <bool PRE>
 __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
     // [A buf0][A buf1][B buf0][B buf1], each 128 rows x 36 floats
     __shared__ __attribute__((aligned(16))) float smem[4 * TILE_ROWS * F32_LD];
@@ -85,12 +87,16 @@ __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
     }
     const uint32_t q0 = q_tile * TILE_QUERIES;
     const uint32_t t0 = split * p.tiles_per_split;
-    const uint32_t t1 = min(t0 + p.tiles_per_split, p.n_tiles);
+    const uint32_t t1 = PRE ? min(min(t0 + p.tiles_per_split, p.n_tiles), t0 + p.pre_tiles)
+                            : min(t0 + p.tiles_per_split, p.n_tiles);
 
     const uint64_t list_stride = (uint64_t)p.n_splits * p.cap;  // between consecutive queries
     uint2* wave_lists = p.lists + ((uint64_t)(q0 + wave * 32) * p.n_splits + split) * p.cap;
     float tau = -INFINITY;
+    if (!PRE && p.tau0) tau = p.tau0[q0 + wave * 32 + l31];
+    if (p.debug & 1u) tau = INFINITY;
     uint32_t cnt = 0;
+    float gmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // PRE: this lane's group maxima
 
     const uint32_t KC = p.dpad / F32_BK;
     const uint32_t total = (t1 > t0 ? (t1 - t0) : 0) * KC;
@@ -160,10 +166,34 @@ __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
         if (c + 1 < total) store_chunk(buf ^ 1);
         __syncthreads();
         if (kc == KC - 1) {
+            if (PRE) {
+                const bool plain = !p.valid && !p.filter && (tile + 1) * TILE_ROWS <= p.n;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                push_tile(acc[mt], tile * TILE_ROWS + mt * 32, h, l31, lane, p, wave_lists, list_stride, tau, cnt);
+                for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        bool ok = true;
+                        if (!plain) {
+                            const uint32_t row = tile * TILE_ROWS + mt * 32 + row_of_reg(r, h);
+                            ok = row < p.n;
+                            if (ok && p.valid) ok = bit_set(p.valid, row);
+                            if (ok && p.filter) ok = bit_set(p.filter, row);
+                        }
+                        if (ok) gmax[mt] = fmaxf(gmax[mt], acc[mt][r]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    push_tile(acc[mt], tile * TILE_ROWS + mt * 32, h, l31, lane, p, wave_lists, list_stride, tau, cnt);
+            }
         }
+    }
+    if (PRE) {
+        float* dst = p.pre_max + (uint64_t)(q0 + wave * 32 + l31) * (8 * p.n_splits) + (split * 2 + h) * 4;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) dst[mt] = gmax[mt];
+        return;
     }
 
     uint64_t need = __builtin_amdgcn_ballot_w64(cnt > p.kprime) & 0xffffffffull;
@@ -178,14 +208,52 @@ __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// One wave per query: tau0 = (kprime-th largest of the query's group maxima) - 2 ulps.
+__global__ __launch_bounds__(64) void tau0_kernel(const float* __restrict__ pre_max, uint32_t groups,
+                                                  uint32_t kprime, float* __restrict__ tau0) {
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    const float* v = pre_max + (uint64_t)q * groups;
+    uint32_t prefix = 0;
+    if (groups >= kprime) {
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t trial = prefix | (1u << bit);
+            uint32_t cnt = 0;
+            for (uint32_t i = 0; i < groups; i += 64) {
+                const bool ge = (i + lane < groups) && (f2ord(v[i + lane]) >= trial);
+                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ge));
+            }
+            if (cnt >= kprime) prefix = trial;
+        }
+    }
+    if (lane == 0) {
+        float t = -INFINITY;
+        // f2ord(-inf) = 0x007fffff; anything at or below it means "no threshold"
+        if (groups >= kprime && prefix > 0x00800001u) t = ord2f(prefix - 2);
+        tau0[q] = t;
+    }
+}
+
 hipError_t launch_flat_scan(int precision, const ScanParams& p, hipStream_t stream) {
     const uint32_t grid = p.n_splits * p.q_tiles;
     if (grid == 0) return hipSuccess;
     if (precision == NEEDLE_PRECISION_FP32) {
-        hipLaunchKernelGGL(flat_scan_f32_kernel, dim3(grid), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(flat_scan_f32_kernel<false>, dim3(grid), dim3(256), 0, stream, p);
     } else {
         return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_flat_prepass(int precision, const ScanParams& p, float* d_tau0, hipStream_t stream) {
+    const uint32_t grid = p.n_splits * p.q_tiles;
+    if (grid == 0) return hipSuccess;
+    if (precision == NEEDLE_PRECISION_FP32) {
+        hipLaunchKernelGGL(flat_scan_f32_kernel<true>, dim3(grid), dim3(256), 0, stream, p);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(tau0_kernel, dim3(p.q_tiles * TILE_QUERIES), dim3(64), 0, stream, p.pre_max, 8 * p.n_splits,
+                       p.kprime, d_tau0);
     return hipGetLastError();
 }
 
@@ -193,7 +261,7 @@ int flat_scan_blocks_per_cu(int precision) {
     int nb = 0;
     hipError_t e = hipErrorInvalidValue;
     if (precision == NEEDLE_PRECISION_FP32)
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, flat_scan_f32_kernel, 256, 0);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, flat_scan_f32_kernel<false>, 256, 0);
     if (e != hipSuccess || nb < 1) nb = 1;
     return nb;
 }

@@ -6,6 +6,8 @@ namespace nh {
 
 // ---- flat_scan.hip ---------------------------------------------------------
 hipError_t launch_flat_scan(int precision, const ScanParams& p, hipStream_t stream);
+// pre-pass over p.pre_tiles tiles per slice (writes p.pre_max), then d_tau0[q_pad]
+hipError_t launch_flat_prepass(int precision, const ScanParams& p, float* d_tau0, hipStream_t stream);
 int flat_scan_blocks_per_cu(int precision);
 uint32_t flat_scan_kstep(int precision);
 
@@ -32,6 +34,7 @@ struct PostParams {
     uint32_t* cand_ids;       // [q][kprime]
     uint32_t* cand_n;         // [q]
     float* tau_star;          // [q]
+    const float* tau0;        // [q] threshold the main pass started from, or null
     uint32_t* flagged;        // [q] query indices failing the bound check
     uint32_t* flag_count;     // [1]
     uint64_t* out_ids;        // [q][k]

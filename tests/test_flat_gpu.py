@@ -83,6 +83,38 @@ def test_readme_shape_cosine_384(ctx, oracle):
     ix.close()
 
 
+@pytest.mark.parametrize("metric", METRICS4)
+def test_long_slices_seeded_threshold(ctx, oracle, metric):
+    """Slices long enough for the threshold-seeding pre-pass, with and without masks."""
+    import needle_amd as na
+
+    n, d, q, k = 150_000, 32, 200, 10
+    base, queries = _data(21, n, d, q, "unit" if metric == "CosineNormalized" else "gauss")
+    m = na.DistanceFunction[metric]
+    rng = np.random.default_rng(3)
+    valid = rng.random(n) > 0.2
+    filt = rng.random(n) < 0.1
+    ix = na.FlatIndex(ctx, base, m)
+    _check(oracle, ix.search(queries, k), base, queries, k, m)
+    ix.set_valid_mask(valid)
+    _check(oracle, ix.search(queries, k, filter_mask=filt), base, queries, k, m, valid=valid, filt=filt)
+    ix.close()
+
+
+def test_sorted_base_worst_case_order(ctx, oracle):
+    """Rows arranged from farthest to nearest: every tile beats the running threshold."""
+    import needle_amd as na
+
+    base, queries = _data(22, 60_000, 24, 8)
+    q0 = queries[0]
+    order = np.argsort(-((base - q0) ** 2).sum(axis=1))
+    base = np.ascontiguousarray(base[order])
+    m = na.DistanceFunction.Euclidean
+    ix = na.FlatIndex(ctx, base, m)
+    _check(oracle, ix.search(queries, 10), base, queries, 10, m)
+    ix.close()
+
+
 def test_gen_vector_inputs(ctx, oracle):
     """The reference's own LCG inputs (src/recall_benchmark.rs:171-180, 237-242)."""
     import needle_amd as na
