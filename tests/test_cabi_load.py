@@ -1,0 +1,63 @@
+"""CPU-side checks of the C ABI: the library loads and exports every symbol the header declares.
+No compute call is made (there is no GPU here, and the library has no CPU path)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "needle_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(needle_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    from needle_amd import _lib
+
+    assert sorted(_lib.EXPORTS) == _header_symbols()
+
+
+def test_library_exports_every_declared_symbol():
+    from needle_amd import _lib
+
+    L = _lib.lib()
+    for sym in _header_symbols():
+        assert hasattr(L, sym), sym
+    assert L.needle_hip_version() >= 100
+
+
+def test_metric_aliases_resolved_by_library():
+    import needle_amd as na
+
+    DF = na.DistanceFunction
+    for s, m in {"cosine": DF.Cosine, "L2": DF.Euclidean, "inner_product": DF.DotProduct, "l1": DF.Manhattan,
+                 "linf": DF.Chebyshev, "CosineNormalized": DF.CosineNormalized, "hamming": DF.Hamming}.items():
+        assert DF.from_str(s) == m
+    with pytest.raises(ValueError):
+        DF.from_str("nope")
+    assert str(DF.DotProduct) == "DotProduct"
+
+
+def test_no_device_fails_loudly():
+    """Without a GPU the product path must refuse to start, not fall back to anything."""
+    import torch
+
+    import needle_amd as na
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(na.NeedleHipError) as e:
+        na.Context(0)
+    assert e.value.status == na._lib.ERR_NO_DEVICE
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "needle_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("the oracle's", ""), os.path.join(dirpath, f)
