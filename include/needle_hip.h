@@ -183,6 +183,36 @@ needle_hip_status needle_hip_batch_search_device(needle_hip_index* index, const 
                                                  uint64_t* d_out_ids, float* d_out_dists,
                                                  uint32_t* d_out_counts);
 
+/* ---- IVF index --------------------------------------------------------- */
+
+/* IvfIndex after train() + insert() of every row, src/indexing/ivf.rs:299-327,
+ * 462-498, for GIVEN centroids (the reference trains them with an unseeded
+ * k-means, ivf.rs:330-450; training output is not part of the parity contract).
+ * base: n x dim host f32; centroids: nlist x dim host f32; assignment: nullable,
+ * assignment[i] = list of row i; NULL -> computed as find_nearest_centroid,
+ * ivf.rs:453-459 (first nearest centroid by Euclidean distance).  Rows are
+ * stored list by list in insertion (row id) order, IVF-Flat, ivf.rs:181-196.
+ * Distances are always Euclidean in distance.rs arithmetic, ivf.rs:67,551. */
+needle_hip_status needle_hip_ivf_build(needle_hip_ctx* ctx, const float* base, uint64_t n, uint32_t dim,
+                                       const float* centroids, uint32_t nlist,
+                                       const uint32_t* assignment, const uint32_t* valid_bitmask,
+                                       needle_hip_index** out);
+
+/* Coarse step of IvfIndex::search, ivf.rs:521-533: for each query the
+ * min(nprobe, nlist) lists nearest by Euclidean distance, ascending, ties to
+ * the lower list id.  out_list_ids is [q][nprobe] (unused tail = UINT32_MAX).
+ * Host pointers. */
+needle_hip_status needle_hip_ivf_probe(needle_hip_index* index, const float* queries, uint32_t q,
+                                       uint32_t query_dim, uint32_t nprobe, uint32_t* out_list_ids,
+                                       uint32_t* out_counts);
+
+/* IvfIndex::cluster_stats sizes, ivf.rs:788-805: rows per list, [nlist]. */
+needle_hip_status needle_hip_ivf_list_sizes(const needle_hip_index* index, uint32_t* out_sizes);
+
+/* needle_hip_batch_search[_device] on an IVF index = IvfIndex::search per query,
+ * ivf.rs:509-567, with params->nprobe: the k nearest rows of the probed lists
+ * by (distance, id). */
+
 /* ---- operator-level calls --------------------------------------------- */
 
 /* GpuAccelerator::batch_{cosine,euclidean}_distance / batch_dot_product,

@@ -28,6 +28,7 @@ EXPORTS = (
     "needle_hip_index_set_valid_mask", "needle_hip_index_destroy", "needle_hip_index_len",
     "needle_hip_index_dimensions", "needle_hip_batch_search", "needle_hip_batch_search_device",
     "needle_hip_batch_distance", "needle_hip_kmeans_assign", "needle_hip_merge_topk_device",
+    "needle_hip_ivf_build", "needle_hip_ivf_probe", "needle_hip_ivf_list_sizes",
 )
 
 
@@ -130,6 +131,12 @@ def lib() -> C.CDLL:
     L.needle_hip_kmeans_assign.argtypes = [vp, i32, vp, u64, vp, u32, u32, vp]
     L.needle_hip_merge_topk_device.restype = i32
     L.needle_hip_merge_topk_device.argtypes = [vp, vp, vp, vp, u32, u32, u32, u32, vp, vp, vp]
+    L.needle_hip_ivf_build.restype = i32
+    L.needle_hip_ivf_build.argtypes = [vp, vp, u64, u32, vp, u32, vp, vp, C.POINTER(vp)]
+    L.needle_hip_ivf_probe.restype = i32
+    L.needle_hip_ivf_probe.argtypes = [vp, vp, u32, u32, u32, vp, vp]
+    L.needle_hip_ivf_list_sizes.restype = i32
+    L.needle_hip_ivf_list_sizes.argtypes = [vp, vp]
     _lib = L
     return L
 

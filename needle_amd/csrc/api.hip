@@ -1,20 +1,7 @@
 // C ABI of libneedle_hip.so (declarations and reference citations:
 // include/needle_hip.h).  Host-side orchestration only; kernels live in
 // flat_scan.hip, flat_post.hip and prep.hip.
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
-#include <new>
-#include <string>
-#include <strings.h>
-#include <vector>
-
-#include "nh_common.h"
-#include "nh_kernels.h"
+#include "nh_api.h"
 
 using namespace nh;
 
@@ -23,7 +10,7 @@ using namespace nh;
 // ---------------------------------------------------------------------------
 static thread_local std::string g_last_error;
 
-static needle_hip_status fail(needle_hip_status st, const char* fmt, ...) {
+needle_hip_status nh::fail(needle_hip_status st, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -32,77 +19,6 @@ static needle_hip_status fail(needle_hip_status st, const char* fmt, ...) {
     g_last_error = buf;
     return st;
 }
-
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t _e = (expr);                                                                \
-        if (_e != hipSuccess)                                                                  \
-            return fail(_e == hipErrorOutOfMemory ? NEEDLE_HIP_ERR_OUT_OF_MEMORY : NEEDLE_HIP_ERR_HIP, \
-                        "HIP error %d (%s) at %s:%d: %s", (int)_e, hipGetErrorString(_e), __FILE__,    \
-                        __LINE__, #expr);                                                      \
-    } while (0)
-
-#define ST_TRY(expr)                              \
-    do {                                          \
-        needle_hip_status _s = (expr);            \
-        if (_s != NEEDLE_HIP_OK) return _s;       \
-    } while (0)
-
-// ---------------------------------------------------------------------------
-// objects
-// ---------------------------------------------------------------------------
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t bytes) {
-        if (bytes <= cap) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) { p = nullptr; return e; }
-        cap = want;
-        return hipSuccess;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-    template <typename T> T* as() const { return (T*)p; }
-};
-
-struct needle_hip_ctx {
-    int device = 0;
-    int n_cu = 256;
-    hipStream_t stream = nullptr;
-    bool profiling = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    needle_hip_metrics m{};
-    std::mutex mu;
-    DevBuf scratch[4];  // operator-level calls
-};
-
-enum IndexKind { KIND_FLAT = 0 };
-
-struct needle_hip_index {
-    needle_hip_ctx* ctx = nullptr;
-    int kind = KIND_FLAT;
-    uint64_t n = 0;
-    uint32_t dim = 0, n_pad = 0;
-    int metric = 0, arith = 0;
-    float* d_raw = nullptr;        // [n_pad][dim], padding rows zero
-    float* d_op_f32 = nullptr;     // [n_pad][dpad_f32] (may alias d_raw)
-    bool op_f32_alias = false;
-    uint16_t* d_op_bf16 = nullptr; // [n_pad][dpad_bf16], built on first use
-    uint32_t dpad_f32 = 0, dpad_bf16 = 0;
-    float* d_cinit = nullptr;      // [n_pad] (Euclidean only)
-    float* d_norms = nullptr;      // [n_pad]
-    uint32_t* d_valid = nullptr;   // live-row bitmask or null
-    float max_norm = 0.0f;
-    float min_pos_norm = 0.0f;
-    std::mutex mu;
-    // per-search workspace (grow-only)
-    DevBuf w_qraw, w_qop, w_qn2, w_lists, w_lcnt, w_cand, w_candn, w_tau, w_flagged, w_flagcnt, w_filter, w_premax, w_tau0;
-    DevBuf x_keys, x_u32, x_u64, x_sel;
-};
-
-static inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
 // ---------------------------------------------------------------------------
 // context
@@ -193,10 +109,14 @@ extern "C" needle_hip_status needle_hip_reset_metrics(needle_hip_ctx* c) {
 // ---------------------------------------------------------------------------
 // flat index build
 // ---------------------------------------------------------------------------
-static void index_free(needle_hip_index* ix) {
+void nh::index_free(needle_hip_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->ctx->device);
     (void)hipStreamSynchronize(ix->ctx->stream);
+    if (ix->centroids) nh::index_free(ix->centroids);
+    if (ix->d_list_pos) (void)hipFree(ix->d_list_pos);
+    if (ix->d_list_len) (void)hipFree(ix->d_list_len);
+    if (ix->d_pos2id) (void)hipFree(ix->d_pos2id);
     if (ix->d_op_f32 && !ix->op_f32_alias) (void)hipFree(ix->d_op_f32);
     if (ix->d_raw) (void)hipFree(ix->d_raw);
     if (ix->d_op_bf16) (void)hipFree(ix->d_op_bf16);
@@ -205,14 +125,15 @@ static void index_free(needle_hip_index* ix) {
     if (ix->d_valid) (void)hipFree(ix->d_valid);
     for (DevBuf* b : {&ix->w_qraw, &ix->w_qop, &ix->w_qn2, &ix->w_lists, &ix->w_lcnt, &ix->w_cand, &ix->w_candn,
                       &ix->w_tau, &ix->w_flagged, &ix->w_flagcnt, &ix->w_filter, &ix->w_premax, &ix->w_tau0, &ix->x_keys, &ix->x_u32,
-                      &ix->x_u64, &ix->x_sel})
+                      &ix->x_u64, &ix->x_sel, &ix->x_mask, &ix->v_probe_ids, &ix->v_probe_d, &ix->v_probe_n, &ix->v_probe32,
+                      &ix->v_items, &ix->v_itemq})
         b->release();
     delete ix;
 }
 
 static bool metric_has_first_pass(int metric) { return metric <= NEEDLE_METRIC_DOT_PRODUCT; }
 
-static needle_hip_status upload_mask(needle_hip_index* ix, const uint32_t* mask_host) {
+needle_hip_status nh::upload_mask(needle_hip_index* ix, const uint32_t* mask_host) {
     if (ix->d_valid) { (void)hipFree(ix->d_valid); ix->d_valid = nullptr; }
     if (!mask_host || ix->n == 0) return NEEDLE_HIP_OK;
     const size_t words = (ix->n + 31) / 32;
@@ -222,21 +143,25 @@ static needle_hip_status upload_mask(needle_hip_index* ix, const uint32_t* mask_
     return NEEDLE_HIP_OK;
 }
 
-// d_raw already holds the rows; derive everything else.
-static needle_hip_status flat_finish_build(needle_hip_index* ix) {
+// d_raw already holds the rows (IVF: all n_pad list-ordered positions); derive everything else.
+needle_hip_status nh::finish_operands(needle_hip_index* ix, bool validate) {
     needle_hip_ctx* c = ix->ctx;
     if (ix->n == 0) return NEEDLE_HIP_OK;
+    const uint64_t rows = ix->kind == KIND_IVF ? ix->n_pad : ix->n;
     uint32_t* d_flag = nullptr;
     HIP_TRY(hipMalloc((void**)&d_flag, 2 * sizeof(uint32_t)));
-    // validate_insert_input, src/collection/validation.rs:44-52: no NaN / Inf rows
-    hipError_t e = launch_validate_rows(ix->d_raw, ix->n, ix->dim, d_flag, c->stream);
-    uint32_t bad = 0xffffffffu;
-    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) { (void)hipFree(d_flag); HIP_TRY(e); }
-    if (bad != 0xffffffffu) {
-        (void)hipFree(d_flag);
-        return fail(NEEDLE_HIP_ERR_INVALID_VECTOR, "Invalid vector: row %u contains NaN or Inf", bad);
+    hipError_t e = hipSuccess;
+    if (validate) {
+        // validate_insert_input, src/collection/validation.rs:44-52: no NaN / Inf rows
+        e = launch_validate_rows(ix->d_raw, rows, ix->dim, d_flag, c->stream);
+        uint32_t bad = 0xffffffffu;
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { (void)hipFree(d_flag); HIP_TRY(e); }
+        if (bad != 0xffffffffu) {
+            (void)hipFree(d_flag);
+            return fail(NEEDLE_HIP_ERR_INVALID_VECTOR, "Invalid vector: row %u contains NaN or Inf", bad);
+        }
     }
     if (!metric_has_first_pass(ix->metric)) { (void)hipFree(d_flag); return NEEDLE_HIP_OK; }
 
@@ -258,7 +183,7 @@ static needle_hip_status flat_finish_build(needle_hip_index* ix) {
     }
     if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, 2 * sizeof(uint32_t), c->stream);
     if (e == hipSuccess)
-        e = launch_row_prep(ix->d_raw, ix->n, ix->dim, ix->dpad_f32, normalize, ix->op_f32_alias ? nullptr : ix->d_op_f32,
+        e = launch_row_prep(ix->d_raw, rows, ix->dim, ix->dpad_f32, normalize, ix->op_f32_alias ? nullptr : ix->d_op_f32,
                             nullptr, ix->d_cinit, ix->d_norms, nullptr, d_flag, c->stream);
     uint32_t bits = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&bits, d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
@@ -314,7 +239,7 @@ extern "C" needle_hip_status needle_hip_flat_build(needle_hip_ctx* c, const floa
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) st = fail(NEEDLE_HIP_ERR_HIP, "HIP error %d (%s) uploading the base", (int)e, hipGetErrorString(e));
     }
-    if (st == NEEDLE_HIP_OK) st = flat_finish_build(ix);
+    if (st == NEEDLE_HIP_OK) st = finish_operands(ix, true);
     if (st == NEEDLE_HIP_OK) st = upload_mask(ix, valid_bitmask);
     if (st != NEEDLE_HIP_OK) { index_free(ix); *out = nullptr; return st; }
     *out = ix;
@@ -351,7 +276,7 @@ extern "C" needle_hip_status needle_hip_flat_build_device(needle_hip_ctx* c, con
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) st = fail(NEEDLE_HIP_ERR_HIP, "HIP error %d (%s) copying the base", (int)e, hipGetErrorString(e));
     }
-    if (st == NEEDLE_HIP_OK) st = flat_finish_build(ix);
+    if (st == NEEDLE_HIP_OK) st = finish_operands(ix, true);
     if (st == NEEDLE_HIP_OK) st = upload_mask(ix, valid_bitmask_host);
     if (st != NEEDLE_HIP_OK) { index_free(ix); *out = nullptr; return st; }
     *out = ix;
@@ -365,14 +290,14 @@ extern "C" needle_hip_status needle_hip_index_set_valid_mask(needle_hip_index* i
     return upload_mask(ix, valid_bitmask);
 }
 
-extern "C" void needle_hip_index_destroy(needle_hip_index* ix) { index_free(ix); }
+extern "C" void needle_hip_index_destroy(needle_hip_index* ix) { nh::index_free(ix); }
 extern "C" uint64_t needle_hip_index_len(const needle_hip_index* ix) { return ix ? ix->n : 0; }
 extern "C" uint32_t needle_hip_index_dimensions(const needle_hip_index* ix) { return ix ? ix->dim : 0; }
 
 // ---------------------------------------------------------------------------
 // search
 // ---------------------------------------------------------------------------
-static uint32_t choose_kprime(uint32_t k, int precision) {
+uint32_t nh::choose_kprime(uint32_t k, int precision) {
     // candidates kept per query by the first pass: k plus slack for the rows
     // whose first-pass order differs from the reference order
     const uint32_t slack = precision == NEEDLE_PRECISION_BF16 ? 54 : 22;
@@ -404,12 +329,15 @@ static SplitPlan plan_splits(uint32_t q_tiles, uint32_t n_tiles, uint32_t slots)
     return best;
 }
 
-static needle_hip_status run_exact(needle_hip_index* ix, const float* d_queries, const uint32_t* d_qsel, uint32_t f_total,
-                                   uint32_t k, const uint32_t* d_filter, uint64_t* d_out_ids, float* d_out_dists,
-                                   uint32_t* d_out_counts) {
+needle_hip_status nh::run_exact(needle_hip_index* ix, const float* d_queries, const uint32_t* d_qsel, uint32_t f_total,
+                                uint32_t k, const uint32_t* d_filter, uint64_t* d_out_ids, float* d_out_dists,
+                                uint32_t* d_out_counts, const uint32_t* d_probe, const uint32_t* d_probe_n,
+                                uint32_t nprobe) {
     needle_hip_ctx* c = ix->ctx;
     if (f_total == 0) return NEEDLE_HIP_OK;
-    const uint32_t n = (uint32_t)ix->n;
+    const bool ivf = ix->kind == KIND_IVF;
+    const uint32_t n = ivf ? ix->n_pad : (uint32_t)ix->n;  // IVF: rows are list-ordered positions
+    const uint32_t mask_words = (n + 31) / 32;
     // slots per round: keep the key workspace near 512 MiB
     uint64_t fmax = (512ull << 20) / ((uint64_t)std::max<uint32_t>(n, 1) * 8ull);
     fmax = std::max<uint64_t>(1, std::min<uint64_t>(fmax, 4096));
@@ -418,6 +346,7 @@ static needle_hip_status run_exact(needle_hip_index* ix, const float* d_queries,
     HIP_TRY(ix->x_u32.ensure((size_t)F * (4 + 256) * sizeof(uint32_t)));
     HIP_TRY(ix->x_u64.ensure((size_t)F * sizeof(uint64_t)));
     HIP_TRY(ix->x_sel.ensure((size_t)F * k * sizeof(uint64_t)));
+    if (ivf) HIP_TRY(ix->x_mask.ensure((size_t)F * mask_words * sizeof(uint32_t)));
     for (uint32_t f0 = 0; f0 < f_total; f0 += F) {
         const uint32_t f = std::min(F, f_total - f0);
         ExactParams p{};
@@ -430,6 +359,16 @@ static needle_hip_status run_exact(needle_hip_index* ix, const float* d_queries,
         p.prefix = ix->x_u64.as<uint64_t>();
         p.sel = ix->x_sel.as<uint64_t>();
         p.f = f; p.n = n; p.dim = ix->dim; p.k = k; p.metric = ix->metric; p.arith = ix->arith;
+        if (ivf) {
+            // rows a query may return = the rows of the lists it probes
+            const uint32_t* sel = d_qsel ? d_qsel + f0 : nullptr;
+            HIP_TRY(launch_ivf_mark_lists(sel, f, d_qsel ? d_probe : d_probe + (size_t)f0 * nprobe,
+                                          d_qsel ? d_probe_n : d_probe_n + f0, nprobe, ix->d_list_pos, ix->d_list_len,
+                                          ix->x_mask.as<uint32_t>(), mask_words, c->stream));
+            p.pos2id = ix->d_pos2id;
+            p.pos_filter = ix->x_mask.as<uint32_t>();
+            p.pos_filter_words = mask_words;
+        }
         if (d_qsel) {  // slots name arbitrary queries of the batch
             p.qsel = d_qsel + f0;
             p.query_raw = d_queries;
@@ -451,9 +390,9 @@ static needle_hip_status ensure_bf16_copy(needle_hip_index* ix) {
 }
 
 // Device-resident search of one batch of at most QB queries.
-static needle_hip_status search_batch_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k,
-                                             int precision, const uint32_t* d_filter, uint64_t* d_out_ids,
-                                             float* d_out_dists, uint32_t* d_out_counts) {
+needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k,
+                                               int precision, const uint32_t* d_filter, uint64_t* d_out_ids,
+                                               float* d_out_dists, uint32_t* d_out_counts) {
     needle_hip_ctx* c = ix->ctx;
     const uint32_t n = (uint32_t)ix->n;
     const uint32_t kprime = choose_kprime(std::min(k, n), precision);
@@ -596,8 +535,14 @@ static needle_hip_status search_device_locked(needle_hip_index* ix, const float*
         const uint32_t QB = 16384;
         for (uint32_t q0 = 0; q0 < q; q0 += QB) {
             const uint32_t qb = std::min(QB, q - q0);
-            ST_TRY(search_batch_device(ix, d_queries + (size_t)q0 * ix->dim, qb, k, precision, d_filter,
-                                       d_out_ids + (size_t)q0 * k, d_out_dists + (size_t)q0 * k, d_out_counts + q0));
+            if (ix->kind == KIND_IVF)
+                ST_TRY(ivf_search_batch_device(ix, d_queries + (size_t)q0 * ix->dim, qb, k, params->nprobe, precision,
+                                               d_filter, d_out_ids + (size_t)q0 * k, d_out_dists + (size_t)q0 * k,
+                                               d_out_counts + q0));
+            else
+                ST_TRY(flat_search_batch_device(ix, d_queries + (size_t)q0 * ix->dim, qb, k, precision, d_filter,
+                                                d_out_ids + (size_t)q0 * k, d_out_dists + (size_t)q0 * k,
+                                                d_out_counts + q0));
         }
     }
     if (c->profiling) {

@@ -1,0 +1,327 @@
+// IVF-Flat on the device (C ABI: include/needle_hip.h, "IVF index").
+//
+// Layout: rows are stored list by list (insertion order inside a list, as
+// IvfCluster::{ids,vectors}, src/indexing/ivf.rs:181-196), every list padded to
+// a whole number of 128-row tiles so that a tile never straddles two lists.
+// pos2id maps a position of that copy back to the row id (~0 for padding).
+//
+// Search = IvfIndex::search, ivf.rs:509-567:
+//   1. coarse: exact flat search of the centroid set with k = nprobe (Euclidean,
+//      ties to the lower list id == the stable sort of ivf.rs:528)
+//   2. list scan, LIST-MAJOR: the (query, probed list) pairs are regrouped by
+//      list; one workgroup multiplies one list's tiles with up to 128 of the
+//      queries probing it, so a list is read once per 128 probing queries rather
+//      than once per query
+//   3. merge of the query's nprobe candidate lists, exact re-scoring, bound
+//      check, exact scan of the probed lists for rejected queries (flat_post.hip)
+#include "nh_api.h"
+
+using namespace nh;
+
+__global__ __launch_bounds__(256) void ivf_gather_rows_kernel(const float* __restrict__ src,
+                                                              const uint32_t* __restrict__ pos2id, uint32_t n_pos,
+                                                              uint32_t dim, float* __restrict__ dst) {
+    const uint32_t pos = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pos >= n_pos) return;
+    const uint32_t id = pos2id[pos];
+    float* d = dst + (uint64_t)pos * dim;
+    if (id == 0xffffffffu) {
+        for (uint32_t i = lane; i < dim; i += 64) d[i] = 0.0f;
+    } else {
+        const float* s = src + (uint64_t)id * dim;
+        for (uint32_t i = lane; i < dim; i += 64) d[i] = s[i];
+    }
+}
+
+__global__ void ivf_narrow_probe_kernel(const uint64_t* __restrict__ ids, uint32_t total, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) out[i] = (uint32_t)ids[i];  // padding UINT64_MAX -> UINT32_MAX
+}
+
+extern "C" needle_hip_status needle_hip_ivf_build(needle_hip_ctx* c, const float* base, uint64_t n, uint32_t dim,
+                                                  const float* centroids, uint32_t nlist, const uint32_t* assignment,
+                                                  const uint32_t* valid_bitmask, needle_hip_index** out) {
+    if (!c || !out) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (dim == 0) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "dimension must be positive");
+    if (nlist == 0 || !centroids) return fail(NEEDLE_HIP_ERR_NOT_TRAINED, "Index not trained");  // IvfError::NotTrained
+    if (n > 0 && !base) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "base is null");
+    if (n >= 0xf0000000ull) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "too many rows for one IVF index");
+    HIP_TRY(hipSetDevice(c->device));
+
+    // insert(): nearest centroid of every row, ivf.rs:474-482
+    std::vector<uint32_t> assign;
+    try {
+        assign.resize(n);
+    } catch (...) {
+        return fail(NEEDLE_HIP_ERR_OUT_OF_MEMORY, "host allocation failed");
+    }
+    if (assignment) {
+        for (uint64_t i = 0; i < n; ++i) {
+            if (assignment[i] >= nlist) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "assignment[%llu] = %u >= nlist", (unsigned long long)i, assignment[i]);
+            assign[i] = assignment[i];
+        }
+    } else if (n > 0) {
+        ST_TRY(needle_hip_kmeans_assign(c, NEEDLE_ARITH_DISTANCE_RS, base, n, centroids, nlist, dim, assign.data()));
+    }
+
+    needle_hip_index* ix = new (std::nothrow) needle_hip_index();
+    if (!ix) return fail(NEEDLE_HIP_ERR_OUT_OF_MEMORY, "host allocation failed");
+    ix->ctx = c;
+    ix->kind = KIND_IVF;
+    ix->n = n;
+    ix->dim = dim;
+    ix->metric = NEEDLE_METRIC_EUCLIDEAN;  // ivf.rs:67: always euclidean_distance
+    ix->arith = NEEDLE_ARITH_DISTANCE_RS;
+    ix->nlist = nlist;
+    ix->list_len.assign(nlist, 0);
+    ix->list_pos.assign(nlist, 0);
+    for (uint64_t i = 0; i < n; ++i) ix->list_len[assign[i]] += 1;
+    uint64_t pos = 0;
+    for (uint32_t l = 0; l < nlist; ++l) {
+        ix->list_pos[l] = (uint32_t)pos;
+        pos += round_up(ix->list_len[l], TILE_ROWS);
+    }
+    if (pos >= 0xfffffff0ull) { index_free(ix); return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "padded IVF layout exceeds 2^32 positions"); }
+    ix->n_pad = (uint32_t)pos;
+    std::vector<uint32_t> pos2id((size_t)ix->n_pad, 0xffffffffu), fill(nlist, 0);
+    for (uint64_t i = 0; i < n; ++i) {  // insertion order inside a list == row id order
+        const uint32_t l = assign[i];
+        pos2id[(size_t)ix->list_pos[l] + fill[l]++] = (uint32_t)i;
+    }
+
+    needle_hip_status st = NEEDLE_HIP_OK;
+    float* d_src = nullptr;
+    auto hip_fail = [&](hipError_t e, const char* what) {
+        return fail(e == hipErrorOutOfMemory ? NEEDLE_HIP_ERR_OUT_OF_MEMORY : NEEDLE_HIP_ERR_HIP, "HIP error %d (%s) %s",
+                    (int)e, hipGetErrorString(e), what);
+    };
+    hipError_t e = hipMalloc((void**)&ix->d_list_pos, sizeof(uint32_t) * nlist);
+    if (e == hipSuccess) e = hipMalloc((void**)&ix->d_list_len, sizeof(uint32_t) * nlist);
+    if (e == hipSuccess) e = hipMemcpyAsync(ix->d_list_pos, ix->list_pos.data(), sizeof(uint32_t) * nlist, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ix->d_list_len, ix->list_len.data(), sizeof(uint32_t) * nlist, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && ix->n_pad > 0) {
+        e = hipMalloc((void**)&ix->d_pos2id, sizeof(uint32_t) * ix->n_pad);
+        if (e == hipSuccess) e = hipMemcpyAsync(ix->d_pos2id, pos2id.data(), sizeof(uint32_t) * ix->n_pad, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMalloc((void**)&ix->d_raw, (size_t)ix->n_pad * dim * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&d_src, (size_t)n * dim * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpyAsync(d_src, base, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            // validate the rows as inserted, then lay them out list by list
+            uint32_t* d_bad = nullptr;
+            e = hipMalloc((void**)&d_bad, sizeof(uint32_t));
+            uint32_t bad = 0xffffffffu;
+            if (e == hipSuccess) e = launch_validate_rows(d_src, n, dim, d_bad, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (d_bad) (void)hipFree(d_bad);
+            if (e == hipSuccess && bad != 0xffffffffu)
+                st = fail(NEEDLE_HIP_ERR_INVALID_VECTOR, "Invalid vector: row %u contains NaN or Inf", bad);
+        }
+        if (e == hipSuccess && st == NEEDLE_HIP_OK) {
+            hipLaunchKernelGGL(ivf_gather_rows_kernel, dim3((ix->n_pad + 3) / 4), dim3(256), 0, c->stream, d_src,
+                               ix->d_pos2id, ix->n_pad, dim, ix->d_raw);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+    }
+    if (d_src) (void)hipFree(d_src);
+    if (e != hipSuccess) st = hip_fail(e, "building the IVF layout");
+    if (st == NEEDLE_HIP_OK) st = finish_operands(ix, false);
+    if (st == NEEDLE_HIP_OK) st = upload_mask(ix, valid_bitmask);
+    if (st == NEEDLE_HIP_OK)
+        st = needle_hip_flat_build(c, centroids, nlist, dim, NEEDLE_METRIC_EUCLIDEAN, NEEDLE_ARITH_DISTANCE_RS, nullptr,
+                                   &ix->centroids);
+    if (st != NEEDLE_HIP_OK) { index_free(ix); return st; }
+    *out = ix;
+    return NEEDLE_HIP_OK;
+}
+
+extern "C" needle_hip_status needle_hip_ivf_list_sizes(const needle_hip_index* ix, uint32_t* out_sizes) {
+    if (!ix || !out_sizes || ix->kind != KIND_IVF) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "not an IVF index");
+    memcpy(out_sizes, ix->list_len.data(), sizeof(uint32_t) * ix->nlist);
+    return NEEDLE_HIP_OK;
+}
+
+// Coarse step on device-resident queries: v_probe32 [q][np] list ids (u32), v_probe_n [q].
+static needle_hip_status ivf_probe_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t np) {
+    needle_hip_ctx* c = ix->ctx;
+    HIP_TRY(ix->v_probe_ids.ensure((size_t)q * np * sizeof(uint64_t)));
+    HIP_TRY(ix->v_probe_d.ensure((size_t)q * np * sizeof(float)));
+    HIP_TRY(ix->v_probe_n.ensure((size_t)q * sizeof(uint32_t)));
+    HIP_TRY(ix->v_probe32.ensure((size_t)q * np * sizeof(uint32_t)));
+    {
+        std::lock_guard<std::mutex> g(ix->centroids->mu);
+        ST_TRY(flat_search_batch_device(ix->centroids, d_queries, q, np, NEEDLE_PRECISION_FP32, nullptr,
+                                        ix->v_probe_ids.as<uint64_t>(), ix->v_probe_d.as<float>(),
+                                        ix->v_probe_n.as<uint32_t>()));
+    }
+    const uint32_t total = q * np;
+    hipLaunchKernelGGL(ivf_narrow_probe_kernel, dim3((total + 255) / 256), dim3(256), 0, c->stream,
+                       ix->v_probe_ids.as<uint64_t>(), total, ix->v_probe32.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    return NEEDLE_HIP_OK;
+}
+
+extern "C" needle_hip_status needle_hip_ivf_probe(needle_hip_index* ix, const float* queries, uint32_t q,
+                                                  uint32_t query_dim, uint32_t nprobe, uint32_t* out_list_ids,
+                                                  uint32_t* out_counts) {
+    if (!ix || ix->kind != KIND_IVF) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "not an IVF index");
+    if (q > 0 && query_dim != ix->dim)
+        return fail(NEEDLE_HIP_ERR_DIMENSION_MISMATCH, "Dimension mismatch: expected %u, got %u", ix->dim, query_dim);
+    if (q == 0) return NEEDLE_HIP_OK;
+    if (!queries || !out_list_ids || !out_counts) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (nprobe == 0) { memset(out_counts, 0, sizeof(uint32_t) * q); return NEEDLE_HIP_OK; }
+    std::lock_guard<std::mutex> g(ix->mu);
+    needle_hip_ctx* c = ix->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t np = std::min(nprobe, ix->nlist);
+    if (np > K_MAX) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "nprobe = %u exceeds %d", np, K_MAX);
+    HIP_TRY(ix->w_qraw.ensure((size_t)q * ix->dim * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(ix->w_qraw.p, queries, (size_t)q * ix->dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    ST_TRY(ivf_probe_device(ix, ix->w_qraw.as<float>(), q, np));
+    std::vector<uint32_t> tmp((size_t)q * np);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), ix->v_probe32.p, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_counts, ix->v_probe_n.p, (size_t)q * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < q; ++i)
+        for (uint32_t j = 0; j < nprobe; ++j)
+            out_list_ids[(size_t)i * nprobe + j] = j < np ? tmp[(size_t)i * np + j] : 0xffffffffu;
+    return NEEDLE_HIP_OK;
+}
+
+needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k,
+                                              uint32_t nprobe, int precision, const uint32_t* d_filter,
+                                              uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts) {
+    needle_hip_ctx* c = ix->ctx;
+    const uint32_t np = std::min(nprobe, ix->nlist);
+    if (np == 0) {  // no list probed: no candidates
+        HIP_TRY(launch_fill_empty(d_out_ids, d_out_dists, d_out_counts, q, k, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return NEEDLE_HIP_OK;
+    }
+    if (np > K_MAX) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "nprobe = %u exceeds %d", np, K_MAX);
+    ST_TRY(ivf_probe_device(ix, d_queries, q, np));
+    const uint32_t* d_probe = ix->v_probe32.as<uint32_t>();
+    const uint32_t* d_probe_n = ix->v_probe_n.as<uint32_t>();
+
+    const uint32_t kprime = choose_kprime(std::min<uint64_t>(k, ix->n), precision);
+    const bool exact_only = precision == NEEDLE_PRECISION_EXACT_SCAN || kprime > KPRIME_MAX ||
+                            (uint64_t)np * kprime * sizeof(uint64_t) > 60000ull;
+    if (exact_only) {
+        ST_TRY(run_exact(ix, d_queries, nullptr, q, k, d_filter, d_out_ids, d_out_dists, d_out_counts, d_probe, d_probe_n, np));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::lock_guard<std::mutex> g(c->mu);
+        c->m.fallback_queries += q;
+        return NEEDLE_HIP_OK;
+    }
+
+    // regroup (query, probed list) pairs by list on the host: q * np small integers
+    std::vector<uint32_t> probe((size_t)q * np), probe_n(q);
+    HIP_TRY(hipMemcpyAsync(probe.data(), d_probe, probe.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(probe_n.data(), d_probe_n, (size_t)q * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> per_list(ix->nlist + 1, 0);
+    for (uint32_t i = 0; i < q; ++i)
+        for (uint32_t s = 0; s < probe_n[i]; ++s) per_list[probe[(size_t)i * np + s] + 1] += 1;
+    for (uint32_t l = 0; l < ix->nlist; ++l) per_list[l + 1] += per_list[l];
+    std::vector<uint2> itemq(per_list[ix->nlist]);
+    {
+        std::vector<uint32_t> fill(per_list.begin(), per_list.end() - 1);
+        for (uint32_t i = 0; i < q; ++i)  // ascending query index inside a list
+            for (uint32_t s = 0; s < probe_n[i]; ++s) itemq[fill[probe[(size_t)i * np + s]]++] = make_uint2(i, s);
+    }
+    std::vector<IvfItem> items;
+    for (uint32_t l = 0; l < ix->nlist; ++l) {
+        const uint32_t cnt = per_list[l + 1] - per_list[l];
+        if (cnt == 0 || ix->list_len[l] == 0) continue;
+        const uint32_t t0 = ix->list_pos[l] / TILE_ROWS, t1 = t0 + round_up(ix->list_len[l], TILE_ROWS) / TILE_ROWS;
+        for (uint32_t o = 0; o < cnt; o += TILE_QUERIES)
+            items.push_back(IvfItem{t0, t1, per_list[l] + o, std::min<uint32_t>(TILE_QUERIES, cnt - o)});
+    }
+
+    const uint32_t dpad = ix->dpad_f32, cap = list_cap(kprime);
+    HIP_TRY(ix->w_qop.ensure((size_t)q * dpad * sizeof(float)));
+    HIP_TRY(ix->w_qn2.ensure((size_t)q * sizeof(double)));
+    HIP_TRY(ix->w_lists.ensure((size_t)q * np * cap * sizeof(uint2)));
+    HIP_TRY(ix->w_lcnt.ensure((size_t)q * np * sizeof(uint32_t)));
+    HIP_TRY(ix->w_cand.ensure((size_t)q * kprime * sizeof(uint32_t)));
+    HIP_TRY(ix->w_candn.ensure((size_t)q * sizeof(uint32_t)));
+    HIP_TRY(ix->w_tau.ensure((size_t)q * sizeof(float)));
+    HIP_TRY(ix->w_flagged.ensure((size_t)q * sizeof(uint32_t)));
+    HIP_TRY(ix->w_flagcnt.ensure(sizeof(uint32_t)));
+    HIP_TRY(ix->v_items.ensure(std::max<size_t>(items.size(), 1) * sizeof(IvfItem)));
+    HIP_TRY(ix->v_itemq.ensure(std::max<size_t>(itemq.size(), 1) * sizeof(uint2)));
+    if (!items.empty())
+        HIP_TRY(hipMemcpyAsync(ix->v_items.p, items.data(), items.size() * sizeof(IvfItem), hipMemcpyHostToDevice, c->stream));
+    if (!itemq.empty())
+        HIP_TRY(hipMemcpyAsync(ix->v_itemq.p, itemq.data(), itemq.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(ix->w_qop.p, 0, (size_t)q * dpad * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(ix->w_lcnt.p, 0, (size_t)q * np * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(ix->w_flagcnt.p, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(launch_row_prep(d_queries, q, ix->dim, dpad, false, ix->w_qop.as<float>(), nullptr, nullptr, nullptr,
+                            ix->w_qn2.as<double>(), nullptr, c->stream));
+
+    ScanParams sp{};
+    sp.base_op = ix->d_op_f32;
+    sp.query_op = ix->w_qop.p;
+    sp.cinit = ix->d_cinit;
+    sp.valid = ix->d_valid;
+    sp.filter = d_filter;
+    sp.lists = ix->w_lists.as<uint2>();
+    sp.list_counts = ix->w_lcnt.as<uint32_t>();
+    sp.n = ix->n_pad;
+    sp.n_tiles = ix->n_pad / TILE_ROWS;
+    sp.dpad = dpad;
+    sp.kprime = kprime;
+    sp.cap = cap;
+    sp.items = ix->v_items.as<IvfItem>();
+    sp.item_queries = ix->v_itemq.as<uint2>();
+    sp.pos2id = ix->d_pos2id;
+    sp.nprobe = np;
+    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(launch_ivf_scan(NEEDLE_PRECISION_FP32, sp, (uint32_t)items.size(), c->stream));
+    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+
+    PostParams pp{};
+    pp.base_raw = ix->d_raw;
+    pp.query_raw = d_queries;
+    pp.qnorm2 = ix->w_qn2.as<double>();
+    pp.lists = sp.lists;
+    pp.list_counts = sp.list_counts;
+    pp.cand_ids = ix->w_cand.as<uint32_t>();
+    pp.cand_n = ix->w_candn.as<uint32_t>();
+    pp.tau_star = ix->w_tau.as<float>();
+    pp.pos2id = ix->d_pos2id;
+    pp.flagged = ix->w_flagged.as<uint32_t>();
+    pp.flag_count = ix->w_flagcnt.as<uint32_t>();
+    pp.out_ids = d_out_ids;
+    pp.out_dists = d_out_dists;
+    pp.out_counts = d_out_counts;
+    pp.q = q; pp.n = ix->n_pad; pp.dim = ix->dim; pp.k = k; pp.kprime = kprime; pp.cap = cap; pp.n_splits = np;
+    pp.metric = ix->metric; pp.arith = ix->arith; pp.precision = NEEDLE_PRECISION_FP32;
+    pp.max_norm = ix->max_norm;
+    HIP_TRY(launch_merge_select(pp, c->stream));
+    HIP_TRY(launch_rescore_finalize(pp, c->stream));
+
+    uint32_t n_flagged = 0;
+    HIP_TRY(hipMemcpyAsync(&n_flagged, pp.flag_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->profiling) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        std::lock_guard<std::mutex> g(c->mu);
+        c->m.scan_launches += 1;
+        c->m.scan_ms_total += ms;
+        c->m.last_scan_ms = ms;
+    }
+    if (n_flagged > 0) {
+        if (n_flagged > q) n_flagged = q;
+        ST_TRY(run_exact(ix, d_queries, pp.flagged, n_flagged, k, d_filter, d_out_ids, d_out_dists, d_out_counts, d_probe,
+                         d_probe_n, np));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::lock_guard<std::mutex> g(c->mu);
+        c->m.fallback_queries += n_flagged;
+    }
+    return NEEDLE_HIP_OK;
+}

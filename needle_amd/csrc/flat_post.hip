@@ -131,9 +131,10 @@ __global__ __launch_bounds__(256) void rescore_finalize_kernel(PostParams p) {
     float d = 0.0f;
     uint32_t id = 0;
     if (j < nc) {
-        id = p.cand_ids[(uint64_t)q * p.kprime + j];
+        const uint32_t pos = p.cand_ids[(uint64_t)q * p.kprime + j];
+        id = p.pos2id ? p.pos2id[pos] : pos;
         d = canon_distance(exact_distance(p.metric, p.arith, p.query_raw + (uint64_t)q * p.dim,
-                                          p.base_raw + (uint64_t)id * p.dim, p.dim));
+                                          p.base_raw + (uint64_t)pos * p.dim, p.dim));
         key = hit_key(d, id);
     }
     if (j < KPRIME_MAX) { skey[j] = key; sdist[j] = d; }
@@ -174,13 +175,16 @@ __global__ __launch_bounds__(256) void exact_keys_kernel(ExactParams p) {
     const uint32_t q = p.qsel ? p.qsel[f] : f;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     bool live = i < p.n;
-    if (live && p.valid) live = bit_set(p.valid, i);
-    if (live && p.filter) live = bit_set(p.filter, i);
+    uint32_t id = i;
+    if (live && p.pos2id) { id = p.pos2id[i]; live = id != 0xffffffffu; }
+    if (live && p.pos_filter) live = bit_set(p.pos_filter + (uint64_t)f * p.pos_filter_words, i);
+    if (live && p.valid) live = bit_set(p.valid, id);
+    if (live && p.filter) live = bit_set(p.filter, id);
     uint64_t key = ~0ull;
     if (live) {
         const float d = canon_distance(exact_distance(p.metric, p.arith, p.query_raw + (uint64_t)q * p.dim,
                                                       p.base_raw + (uint64_t)i * p.dim, p.dim));
-        key = hit_key(d, i);
+        key = hit_key(d, id);
     }
     if (i < p.n) p.keys[(uint64_t)f * p.n + i] = key;
     const uint64_t m = __builtin_amdgcn_ballot_w64(live);
@@ -286,6 +290,38 @@ hipError_t launch_exact_scan(const ExactParams& p, hipStream_t stream) {
     }
     hipLaunchKernelGGL(exact_gather_kernel, dim3(hb, p.f), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(exact_emit_kernel, dim3(p.f), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// Position bitmask of the rows in the lists a query probes (one slot per query
+// being re-run on the exact scan).  Lists start on 128-row boundaries, so no two
+// lists share a mask word.
+__global__ __launch_bounds__(256) void ivf_mark_lists_kernel(const uint32_t* __restrict__ qsel,
+                                                             const uint32_t* __restrict__ probe,
+                                                             const uint32_t* __restrict__ probe_n, uint32_t nprobe,
+                                                             const uint32_t* __restrict__ list_pos,
+                                                             const uint32_t* __restrict__ list_len,
+                                                             uint32_t* __restrict__ mask, uint32_t words) {
+    const uint32_t f = blockIdx.y, s = blockIdx.x;
+    const uint32_t q = qsel ? qsel[f] : f;
+    if (s >= probe_n[q]) return;
+    const uint32_t l = probe[(uint64_t)q * nprobe + s];
+    const uint32_t p0 = list_pos[l], len = list_len[l];
+    uint32_t* m = mask + (uint64_t)f * words + (p0 >> 5);
+    for (uint32_t w = threadIdx.x; w * 32 < len; w += 256) {
+        const uint32_t rem = len - w * 32;
+        m[w] = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+    }
+}
+
+hipError_t launch_ivf_mark_lists(const uint32_t* d_qsel, uint32_t f, const uint32_t* d_probe, const uint32_t* d_probe_n,
+                                 uint32_t nprobe, const uint32_t* d_list_pos, const uint32_t* d_list_len,
+                                 uint32_t* d_mask, uint32_t words, hipStream_t stream) {
+    if (f == 0 || nprobe == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(d_mask, 0, (size_t)f * words * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ivf_mark_lists_kernel, dim3(nprobe, f), dim3(256), 0, stream, d_qsel, d_probe, d_probe_n, nprobe,
+                       d_list_pos, d_list_len, d_mask, words);
     return hipGetLastError();
 }
 

@@ -1,15 +1,21 @@
-// First pass of the exact flat search: scores = base x queries^T on the matrix
+// First pass of the exact searches: scores = rows x queries^T on the matrix
 // cores, with the per-query candidate selection fused behind each tile.
 //
-// One workgroup = 4 waves = a stationary block of 128 queries walking a slice of
-// the base in tiles of 128 rows.  The base rows are the MFMA A operand (rows of
-// the 32x32 result land in the accumulator registers), the queries are the B
-// operand (one query per lane), so each lane compares its 16 results per tile
-// against ITS query's running threshold with no cross-lane traffic.  A result
-// above the threshold is appended to that query's candidate list; a list that
-// grows past 2*kprime is cut back to its kprime best entries by the owning wave
+// One workgroup = 4 waves = a block of up to 128 queries walking a run of row
+// tiles (128 rows each).  The rows are the MFMA A operand (rows of the 32x32
+// result land in the accumulator registers), the queries are the B operand (one
+// query per lane), so each lane compares its 16 results per tile against ITS
+// query's running threshold with no cross-lane traffic.  A result above the
+// threshold is appended to that query's candidate list; a list that grows past
+// 2*kprime is cut back to its kprime best entries by the owning wave
 // (nh_select.h), which also raises the threshold.  Waves own disjoint queries,
 // so the selection needs no LDS, no atomics and no workgroup barrier.
+//
+// Two work decompositions share the kernel:
+//   FLAT: workgroup = (query block, slice of the base); queries q0..q0+127.
+//   IVF : workgroup = one work item: the tiles of ONE inverted list x up to 128
+//         of the queries probing it (gathered by index); rows are positions in
+//         the list-ordered copy of the base.
 //
 // The scores are only a filter: the kept candidates are re-scored in the
 // reference's scalar order afterwards (flat_post.hip).
@@ -22,27 +28,46 @@ namespace nh {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+enum ScanMode { MODE_FLAT = 0, MODE_PRE = 1, MODE_IVF = 2 };
+
 // accumulator register r of lane half h holds result row (r&3) + 8*(r>>2) + 4*h
 __device__ inline uint32_t row_of_reg(int r, uint32_t h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// May row `row` be returned?  FLAT: row < n and mask bits of the row; IVF: the
+// position maps to a real row whose mask bits (by original id) are set.
+template <int MODE>
+__device__ inline bool row_live(const ScanParams& p, uint32_t row) {
+    if (MODE == MODE_IVF) {
+        const uint32_t id = p.pos2id[row];
+        if (id == 0xffffffffu) return false;
+        if (p.valid && !bit_set(p.valid, id)) return false;
+        if (p.filter && !bit_set(p.filter, id)) return false;
+        return true;
+    }
+    if (row >= p.n) return false;
+    if (p.valid && !bit_set(p.valid, row)) return false;
+    if (p.filter && !bit_set(p.filter, row)) return false;
+    return true;
+}
+
 // Append the passing results of one 32x32 tile (16 accumulator registers per
-// lane) and compact the lists that filled up.  `acc` rows are base rows
-// row_base + row_of_reg(r, h), the lane's query is column l31 of the wave.
+// lane) and compact the lists that filled up.  `acc` rows are rows
+// row_base + row_of_reg(r, h); the lane's query owns candidate list `list_idx`.
+template <int MODE>
 __device__ inline void push_tile(const f32x16& acc, uint32_t row_base, uint32_t h, uint32_t l31,
-                                 uint32_t lane, const ScanParams& p, uint2* __restrict__ wave_lists,
-                                 uint64_t list_stride, float& tau, uint32_t& cnt) {
+                                 uint32_t lane, const ScanParams& p, uint32_t list_idx, float& tau,
+                                 uint32_t& cnt) {
     float m = acc[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
     if (__builtin_amdgcn_ballot_w64(m > tau) == 0) return;  // wave-uniform
-    uint2* mylist = wave_lists + (uint64_t)l31 * list_stride;
+    uint2* mylist = p.lists + (uint64_t)list_idx * p.cap;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float key = acc[r];
         const uint32_t row = row_base + row_of_reg(r, h);
-        bool pass = (key > tau) && (row < p.n);
-        if (pass && p.valid) pass = bit_set(p.valid, row);
-        if (pass && p.filter) pass = bit_set(p.filter, row);
+        bool pass = key > tau;
+        if (pass) pass = row_live<MODE>(p, row);
         const uint64_t pm = __builtin_amdgcn_ballot_w64(pass);
         if (pm != 0) {
             // lanes l31 and l31+32 serve the same query: the low half takes the
@@ -57,7 +82,8 @@ __device__ inline void push_tile(const f32x16& acc, uint32_t row_base, uint32_t 
         const uint32_t b = (uint32_t)__builtin_ctzll(need);
         need &= need - 1;
         const uint32_t n_e = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)b);
-        const float t = wave_compact_list(wave_lists + (uint64_t)b * list_stride, n_e, p.kprime, lane);
+        const uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)list_idx, (int)b);
+        const float t = wave_compact_list(p.lists + (uint64_t)li * p.cap, n_e, p.kprime, lane);
         if (l31 == b) { tau = t; cnt = p.kprime; }
     }
 }
@@ -68,35 +94,60 @@ __device__ inline void push_tile(const f32x16& acc, uint32_t row_base, uint32_t 
 constexpr int F32_BK = 32;  // k-step staged per LDS buffer
 constexpr int F32_LD = 36;  // padded LDS row stride (floats): conflict-free ds_read_b128
 
-// PRE = true: threshold-seeding pre-pass (group maxima only, no candidate lists).
-template <bool PRE>
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
     // [A buf0][A buf1][B buf0][B buf1], each 128 rows x 36 floats
     __shared__ __attribute__((aligned(16))) float smem[4 * TILE_ROWS * F32_LD];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t l31 = lane & 31, h = lane >> 5;
+    const uint32_t jq = wave * 32 + l31;  // this lane's query slot within the block
 
-    uint32_t split, q_tile;
-    if (p.xcd_map) {
-        const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        split = xcd + 8 * (j / p.q_tiles);
-        q_tile = j % p.q_tiles;
+    uint32_t t0, t1, split = 0, q0 = 0;
+    uint32_t list_idx = 0;       // candidate list of this lane's query
+    uint32_t my_query = 0;       // row of query_op this lane's column multiplies
+    bool q_live = true;          // false: padding slot of an IVF item
+    uint32_t qrow[4];            // query_op rows this thread stages (r = (tid + 256 i) >> 3)
+    if (MODE == MODE_IVF) {
+        const IvfItem it = p.items[blockIdx.x];
+        t0 = it.tile0;
+        t1 = it.tile1;
+        const uint2* iq = p.item_queries + it.qoff;
+        q_live = jq < it.nq;
+        if (q_live) {
+            const uint2 e = iq[jq];
+            my_query = e.x;
+            list_idx = e.x * p.nprobe + e.y;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t r = (tid + i * 256) >> 3;
+            qrow[i] = r < it.nq ? iq[r].x : 0xffffffffu;
+        }
     } else {
-        split = blockIdx.x / p.q_tiles;
-        q_tile = blockIdx.x % p.q_tiles;
+        uint32_t q_tile;
+        if (p.xcd_map) {
+            const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+            split = xcd + 8 * (j / p.q_tiles);
+            q_tile = j % p.q_tiles;
+        } else {
+            split = blockIdx.x / p.q_tiles;
+            q_tile = blockIdx.x % p.q_tiles;
+        }
+        q0 = q_tile * TILE_QUERIES;
+        t0 = split * p.tiles_per_split;
+        t1 = min(t0 + p.tiles_per_split, p.n_tiles);
+        if (MODE == MODE_PRE) t1 = min(t1, t0 + p.pre_tiles);
+        my_query = q0 + jq;
+        list_idx = my_query * p.n_splits + split;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qrow[i] = q0 + ((tid + i * 256) >> 3);
     }
-    const uint32_t q0 = q_tile * TILE_QUERIES;
-    const uint32_t t0 = split * p.tiles_per_split;
-    const uint32_t t1 = PRE ? min(min(t0 + p.tiles_per_split, p.n_tiles), t0 + p.pre_tiles)
-                            : min(t0 + p.tiles_per_split, p.n_tiles);
 
-    const uint64_t list_stride = (uint64_t)p.n_splits * p.cap;  // between consecutive queries
-    uint2* wave_lists = p.lists + ((uint64_t)(q0 + wave * 32) * p.n_splits + split) * p.cap;
     float tau = -INFINITY;
-    if (!PRE && p.tau0) tau = p.tau0[q0 + wave * 32 + l31];
-    if (p.debug & 1u) tau = INFINITY;
+    if (MODE != MODE_PRE && p.tau0 && q_live) tau = p.tau0[my_query];
+    if (!q_live || (p.debug & 1u)) tau = INFINITY;
     uint32_t cnt = 0;
-    float gmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // PRE: this lane's group maxima
+    float gmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // MODE_PRE: this lane's group maxima
 
     const uint32_t KC = p.dpad / F32_BK;
     const uint32_t total = (t1 > t0 ? (t1 - t0) : 0) * KC;
@@ -110,7 +161,11 @@ __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
         for (int i = 0; i < 4; ++i) {
             const uint32_t idx = tid + i * 256, r = idx >> 3, c4 = idx & 7;
             ra[i] = *(const f32x4*)(gA + (uint64_t)(tile * TILE_ROWS + r) * p.dpad + kc * F32_BK + c4 * 4);
-            rb[i] = *(const f32x4*)(gB + (uint64_t)(q0 + r) * p.dpad + kc * F32_BK + c4 * 4);
+            if (MODE == MODE_IVF && qrow[i] == 0xffffffffu) {
+                rb[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            } else {
+                rb[i] = *(const f32x4*)(gB + (uint64_t)qrow[i] * p.dpad + kc * F32_BK + c4 * 4);
+            }
         }
     };
     auto store_chunk = [&](uint32_t buf) {
@@ -166,31 +221,26 @@ __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
         if (c + 1 < total) store_chunk(buf ^ 1);
         __syncthreads();
         if (kc == KC - 1) {
-            if (PRE) {
+            if (MODE == MODE_PRE) {
                 const bool plain = !p.valid && !p.filter && (tile + 1) * TILE_ROWS <= p.n;
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         bool ok = true;
-                        if (!plain) {
-                            const uint32_t row = tile * TILE_ROWS + mt * 32 + row_of_reg(r, h);
-                            ok = row < p.n;
-                            if (ok && p.valid) ok = bit_set(p.valid, row);
-                            if (ok && p.filter) ok = bit_set(p.filter, row);
-                        }
+                        if (!plain) ok = row_live<MODE_FLAT>(p, tile * TILE_ROWS + mt * 32 + row_of_reg(r, h));
                         if (ok) gmax[mt] = fmaxf(gmax[mt], acc[mt][r]);
                     }
                 }
             } else {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
-                    push_tile(acc[mt], tile * TILE_ROWS + mt * 32, h, l31, lane, p, wave_lists, list_stride, tau, cnt);
+                    push_tile<MODE>(acc[mt], tile * TILE_ROWS + mt * 32, h, l31, lane, p, list_idx, tau, cnt);
             }
         }
     }
-    if (PRE) {
-        float* dst = p.pre_max + (uint64_t)(q0 + wave * 32 + l31) * (8 * p.n_splits) + (split * 2 + h) * 4;
+    if (MODE == MODE_PRE) {
+        float* dst = p.pre_max + (uint64_t)my_query * (8 * p.n_splits) + (split * 2 + h) * 4;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) dst[mt] = gmax[mt];
         return;
@@ -201,13 +251,13 @@ __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
         const uint32_t b = (uint32_t)__builtin_ctzll(need);
         need &= need - 1;
         const uint32_t n_e = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)b);
-        wave_compact_list(wave_lists + (uint64_t)b * list_stride, n_e, p.kprime, lane);
+        const uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)list_idx, (int)b);
+        wave_compact_list(p.lists + (uint64_t)li * p.cap, n_e, p.kprime, lane);
         if (l31 == b) cnt = p.kprime;
     }
-    if (h == 0) p.list_counts[(uint64_t)(q0 + wave * 32 + l31) * p.n_splits + split] = cnt;
+    if (h == 0 && q_live) p.list_counts[list_idx] = cnt;
 }
 
-// ---------------------------------------------------------------------------
 // One wave per query: tau0 = (kprime-th largest of the query's group maxima) - 2 ulps.
 __global__ __launch_bounds__(64) void tau0_kernel(const float* __restrict__ pre_max, uint32_t groups,
                                                   uint32_t kprime, float* __restrict__ tau0) {
@@ -237,7 +287,7 @@ hipError_t launch_flat_scan(int precision, const ScanParams& p, hipStream_t stre
     const uint32_t grid = p.n_splits * p.q_tiles;
     if (grid == 0) return hipSuccess;
     if (precision == NEEDLE_PRECISION_FP32) {
-        hipLaunchKernelGGL(flat_scan_f32_kernel<false>, dim3(grid), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(flat_scan_f32_kernel<MODE_FLAT>, dim3(grid), dim3(256), 0, stream, p);
     } else {
         return hipErrorInvalidValue;
     }
@@ -248,7 +298,7 @@ hipError_t launch_flat_prepass(int precision, const ScanParams& p, float* d_tau0
     const uint32_t grid = p.n_splits * p.q_tiles;
     if (grid == 0) return hipSuccess;
     if (precision == NEEDLE_PRECISION_FP32) {
-        hipLaunchKernelGGL(flat_scan_f32_kernel<true>, dim3(grid), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(flat_scan_f32_kernel<MODE_PRE>, dim3(grid), dim3(256), 0, stream, p);
     } else {
         return hipErrorInvalidValue;
     }
@@ -257,11 +307,18 @@ hipError_t launch_flat_prepass(int precision, const ScanParams& p, float* d_tau0
     return hipGetLastError();
 }
 
+hipError_t launch_ivf_scan(int precision, const ScanParams& p, uint32_t n_items, hipStream_t stream) {
+    if (n_items == 0) return hipSuccess;
+    if (precision != NEEDLE_PRECISION_FP32) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(flat_scan_f32_kernel<MODE_IVF>, dim3(n_items), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 int flat_scan_blocks_per_cu(int precision) {
     int nb = 0;
     hipError_t e = hipErrorInvalidValue;
     if (precision == NEEDLE_PRECISION_FP32)
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, flat_scan_f32_kernel<false>, 256, 0);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, flat_scan_f32_kernel<MODE_FLAT>, 256, 0);
     if (e != hipSuccess || nb < 1) nb = 1;
     return nb;
 }

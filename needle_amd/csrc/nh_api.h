@@ -1,0 +1,119 @@
+// Internal host-side definitions shared by the C ABI translation units.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <strings.h>
+#include <vector>
+
+#include "nh_common.h"
+#include "nh_kernels.h"
+
+namespace nh {
+
+needle_hip_status fail(needle_hip_status st, const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return nh::fail(_e == hipErrorOutOfMemory ? NEEDLE_HIP_ERR_OUT_OF_MEMORY : NEEDLE_HIP_ERR_HIP, \
+                            "HIP error %d (%s) at %s:%d: %s", (int)_e, hipGetErrorString(_e), __FILE__,    \
+                            __LINE__, #expr);                                                  \
+    } while (0)
+
+#define ST_TRY(expr)                              \
+    do {                                          \
+        needle_hip_status _s = (expr);            \
+        if (_s != NEEDLE_HIP_OK) return _s;       \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+}  // namespace nh
+
+struct needle_hip_ctx {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    bool profiling = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    needle_hip_metrics m{};
+    std::mutex mu;
+    nh::DevBuf scratch[4];  // operator-level calls
+};
+
+enum IndexKind { KIND_FLAT = 0, KIND_IVF = 1 };
+
+struct needle_hip_index {
+    needle_hip_ctx* ctx = nullptr;
+    int kind = KIND_FLAT;
+    uint64_t n = 0;                // rows
+    uint32_t dim = 0;
+    uint32_t n_pad = 0;            // rows of the device copies (flat: n rounded up to 128; IVF: padded positions)
+    int metric = 0, arith = 0;
+    float* d_raw = nullptr;        // [n_pad][dim], padding rows zero (IVF: list-ordered)
+    float* d_op_f32 = nullptr;     // [n_pad][dpad_f32] (may alias d_raw)
+    bool op_f32_alias = false;
+    uint16_t* d_op_bf16 = nullptr; // [n_pad][dpad_bf16], built on first use
+    uint32_t dpad_f32 = 0, dpad_bf16 = 0;
+    float* d_cinit = nullptr;      // [n_pad] (Euclidean only)
+    float* d_norms = nullptr;      // [n_pad]
+    uint32_t* d_valid = nullptr;   // live-row bitmask (by row id) or null
+    float max_norm = 0.0f;
+    std::mutex mu;
+    // IVF
+    needle_hip_index* centroids = nullptr;  // flat Euclidean index over the centroids (probing)
+    uint32_t nlist = 0;
+    std::vector<uint32_t> list_pos, list_len;  // start position (multiple of 128) and rows of every list
+    uint32_t* d_list_pos = nullptr;
+    uint32_t* d_list_len = nullptr;
+    uint32_t* d_pos2id = nullptr;  // [n_pad] row id of a position, ~0 for padding
+    // per-search workspace (grow-only)
+    nh::DevBuf w_qraw, w_qop, w_qn2, w_lists, w_lcnt, w_cand, w_candn, w_tau, w_flagged, w_flagcnt, w_filter, w_premax,
+        w_tau0;
+    nh::DevBuf x_keys, x_u32, x_u64, x_sel, x_mask;
+    nh::DevBuf v_probe_ids, v_probe_d, v_probe_n, v_probe32, v_items, v_itemq;
+};
+
+namespace nh {
+// flat search of one batch (api.hip); used by the IVF probe step as well
+needle_hip_status flat_search_batch_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k,
+                                           int precision, const uint32_t* d_filter, uint64_t* d_out_ids,
+                                           float* d_out_dists, uint32_t* d_out_counts);
+// exact scan of f_total slots; IVF: d_probe/d_probe_n name the lists each query may draw rows from
+needle_hip_status run_exact(needle_hip_index* ix, const float* d_queries, const uint32_t* d_qsel, uint32_t f_total,
+                            uint32_t k, const uint32_t* d_filter, uint64_t* d_out_ids, float* d_out_dists,
+                            uint32_t* d_out_counts, const uint32_t* d_probe = nullptr,
+                            const uint32_t* d_probe_n = nullptr, uint32_t nprobe = 0);
+uint32_t choose_kprime(uint32_t k, int precision);
+void index_free(needle_hip_index* ix);
+needle_hip_status finish_operands(needle_hip_index* ix, bool validate);
+needle_hip_status upload_mask(needle_hip_index* ix, const uint32_t* mask_host);
+// IVF search of one batch (api_ivf.hip)
+needle_hip_status ivf_search_batch_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k,
+                                          uint32_t nprobe, int precision, const uint32_t* d_filter,
+                                          uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts);
+}  // namespace nh

@@ -56,6 +56,12 @@ __device__ inline bool bit_set(const uint32_t* __restrict__ mask, uint32_t i) {
     return (mask[i >> 5] >> (i & 31)) & 1u;
 }
 
+// One unit of the inverted-list scan.
+struct IvfItem {
+    uint32_t tile0, tile1;   // row tiles [tile0, tile1) of the list (lists are padded to whole tiles)
+    uint32_t qoff, nq;       // entries [qoff, qoff + nq) of item_queries, nq <= TILE_QUERIES
+};
+
 // ---- launch parameters of the first-pass scan ----------------------------
 struct ScanParams {
     const void* base_op;      // [n_pad][dpad] operand copy (f32 or bf16), zero padded
@@ -81,6 +87,12 @@ struct ScanParams {
     float* pre_max;           // [q_pad][8 * n_splits] (pre-pass output)
     const float* tau0;        // [q_pad] starting threshold of the main pass, or null
     uint32_t pre_tiles;
+    // inverted-list scan: one workgroup per work item = (one list's row tiles) x (<= 128 of the
+    // queries probing that list); rows are positions in the list-ordered copy of the base
+    const IvfItem* items;     // [grid]
+    const uint2* item_queries;  // (query index, probe slot) per item entry
+    const uint32_t* pos2id;   // [n_pad] original row id of a position, ~0 for padding
+    uint32_t nprobe;          // candidate list of (query, slot) is lists[(query * nprobe + slot) * cap]
 };
 
 }  // namespace nh

@@ -8,6 +8,8 @@ namespace nh {
 hipError_t launch_flat_scan(int precision, const ScanParams& p, hipStream_t stream);
 // pre-pass over p.pre_tiles tiles per slice (writes p.pre_max), then d_tau0[q_pad]
 hipError_t launch_flat_prepass(int precision, const ScanParams& p, float* d_tau0, hipStream_t stream);
+// inverted-list scan: one workgroup per p.items[i]
+hipError_t launch_ivf_scan(int precision, const ScanParams& p, uint32_t n_items, hipStream_t stream);
 int flat_scan_blocks_per_cu(int precision);
 uint32_t flat_scan_kstep(int precision);
 
@@ -35,6 +37,7 @@ struct PostParams {
     uint32_t* cand_n;         // [q]
     float* tau_star;          // [q]
     const float* tau0;        // [q] threshold the main pass started from, or null
+    const uint32_t* pos2id;   // candidates are positions of a list-ordered copy: their row ids, or null
     uint32_t* flagged;        // [q] query indices failing the bound check
     uint32_t* flag_count;     // [1]
     uint64_t* out_ids;        // [q][k]
@@ -56,6 +59,9 @@ struct ExactParams {
     const uint32_t* qsel;     // [f] query index of each slot, or null (slot == query)
     const uint32_t* valid;
     const uint32_t* filter;
+    const uint32_t* pos2id;   // rows are positions of a list-ordered copy: their row ids (~0 padding), or null
+    const uint32_t* pos_filter;  // [f][pos_filter_words] per-slot bitmask over positions, or null
+    uint32_t pos_filter_words;
     uint64_t* keys;           // [f][n] workspace
     uint32_t* live;           // [f]
     uint32_t* k_eff;          // [f]
@@ -71,6 +77,11 @@ struct ExactParams {
     int metric, arith;
 };
 hipError_t launch_exact_scan(const ExactParams& p, hipStream_t stream);
+
+// For each slot f (query qsel[f]) set the position bits of the rows of its probed lists.
+hipError_t launch_ivf_mark_lists(const uint32_t* d_qsel, uint32_t f, const uint32_t* d_probe, const uint32_t* d_probe_n,
+                                 uint32_t nprobe, const uint32_t* d_list_pos, const uint32_t* d_list_len,
+                                 uint32_t* d_mask, uint32_t words, hipStream_t stream);
 
 // One query against n rows, raw distances (dot product positive).
 hipError_t launch_batch_distance(const float* d_query, const float* d_base, uint64_t n, uint32_t dim,

@@ -1,0 +1,147 @@
+"""Parity of the device IVF index (assignment, probe lists, list scan) against the CPU oracle's
+restatement of src/indexing/ivf.rs, through the C ABI.  Bar: identical assignment, identical probe
+lists, ids bit-exact and distances bit-equal."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+F = np.float32
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import needle_amd as na
+
+    c = na.Context(0)
+    yield c
+    c.close()
+
+
+def _setup(oracle, ctx, n, d, nlist, nprobe, seed, kind="uniform"):
+    from needle_amd.ivf import IvfConfig, IvfIndex
+
+    rng = np.random.default_rng(seed)
+    base = rng.random((n, d), dtype=F) if kind == "uniform" else rng.standard_normal((n, d)).astype(F)
+    cents = oracle.ivf_kmeans(base[: min(n, 20 * nlist)], nlist, max_iter=10, seed=seed)
+    ix = IvfIndex(d, IvfConfig.new(cents.shape[0]).with_nprobe(nprobe), ctx=ctx)
+    ix.set_centroids(cents)
+    ix.add(range(n), base)
+    assign = oracle.ivf_assign(base, cents)
+    offsets, order = oracle.ivf_lists_from_assignment(assign, cents.shape[0])
+    return base, cents, ix, assign, offsets, order
+
+
+def _check_search(oracle, ix, base, cents, offsets, order, queries, nprobe, k, **kw):
+    ids, dists, counts = ix.batch_search_arrays(queries, k, **kw)
+    oi, od, oc = oracle.ivf_batch_search(queries, base, cents, offsets, order, nprobe, k)
+    assert np.array_equal(counts, oc), (counts[:8], oc[:8])
+    for i in range(queries.shape[0]):
+        c = int(oc[i])
+        assert np.array_equal(ids[i, :c], oi[i, :c]), (i, ids[i, :c], oi[i, :c])
+        assert np.array_equal(dists[i, :c].view(np.uint32), od[i, :c].view(np.uint32)), (i, dists[i, :c], od[i, :c])
+
+
+@pytest.mark.parametrize("shape", [(3000, 32, 16, 4, 10), (20000, 64, 64, 8, 10), (5000, 100, 40, 40, 5)])
+def test_assignment_probe_and_search(ctx, oracle, shape):
+    n, d, nlist, nprobe, k = shape
+    base, cents, ix, assign, offsets, order = _setup(oracle, ctx, n, d, nlist, nprobe, seed=n)
+    # insert(): nearest centroid of every row (ivf.rs:453-498)
+    got_assign = ctx.kmeans_assign(base, cents, 0)
+    assert np.array_equal(got_assign, assign)
+    assert np.array_equal(ix.cluster_sizes(), np.diff(offsets).astype(np.uint32))
+    rng = np.random.default_rng(1)
+    queries = np.concatenate([base[:5], rng.random((60, d), dtype=F)])
+    # identical probe lists (ivf.rs:521-533)
+    probes = ix.probe(queries)
+    for i in range(queries.shape[0]):
+        assert np.array_equal(probes[i], oracle.ivf_probe(queries[i], cents, nprobe)), i
+    _check_search(oracle, ix, base, cents, offsets, order, queries, nprobe, k)
+    ix.close()
+
+
+def test_reference_kat_self_query_found(ctx, oracle):  # ivf.rs:729-765: nprobe = nlist, k = n
+    base, cents, ix, _, offsets, order = _setup(oracle, ctx, 100, 32, 4, 4, seed=7)
+    res = ix.search(base[0], 100)
+    assert len(res) == 100 and res[0][1] < 1.0
+    hit = [r for r in res if r[0] == 0]
+    assert hit and hit[0][1] < 0.1
+    _check_search(oracle, ix, base, cents, offsets, order, base[:3], 4, 100)
+    ix.close()
+
+
+def test_all_lists_probed_equals_flat(ctx, oracle):
+    base, cents, ix, _, offsets, order = _setup(oracle, ctx, 4000, 24, 8, 8, seed=3, kind="gauss")
+    rng = np.random.default_rng(2)
+    queries = rng.standard_normal((20, 24)).astype(F)
+    ids, dists, counts = ix.batch_search_arrays(queries, 7)
+    fi, fd, fc = oracle.flat_batch_search(queries, base, 7, oracle.EUCLIDEAN)
+    assert np.array_equal(ids, fi) and np.array_equal(dists.view(np.uint32), fd.view(np.uint32))
+    ix.close()
+
+
+def test_edges_k_nprobe_empty_lists(ctx, oracle):
+    from needle_amd.ivf import IvfConfig, IvfIndex
+    import needle_amd as na
+
+    base, cents, ix, _, offsets, order = _setup(oracle, ctx, 600, 16, 6, 2, seed=5)
+    rng = np.random.default_rng(4)
+    queries = rng.random((9, 16), dtype=F)
+    ids, _, counts = ix.batch_search_arrays(queries, 0)  # k == 0 -> empty (ivf.rs:852-866)
+    assert ids.shape == (9, 0) and counts.tolist() == [0] * 9
+    _check_search(oracle, ix, base, cents, offsets, order, queries, 2, 500)  # k above the probed rows
+    with pytest.raises(na.DimensionMismatch):  # ivf.rs:514-519
+        ix.batch_search_arrays(np.zeros((1, 15), dtype=F), 3)
+    ix.close()
+    # far-away centroids own no rows: empty lists are probed and contribute nothing
+    cents2 = np.concatenate([cents, np.full((3, 16), 50.0, dtype=F)])
+    ix2 = IvfIndex(16, IvfConfig.new(9).with_nprobe(9), ctx=ctx)
+    ix2.set_centroids(cents2)
+    ix2.add(range(600), base)
+    a2 = oracle.ivf_assign(base, cents2)
+    off2, ord2 = oracle.ivf_lists_from_assignment(a2, 9)
+    _check_search(oracle, ix2, base, cents2, off2, ord2, queries, 9, 10)
+    ix2.close()
+    empty = IvfIndex(16, IvfConfig.new(6), ctx=ctx)  # NotTrained (ivf.rs:808-850)
+    with pytest.raises(na.NeedleHipError):
+        empty.insert(0, base[0])
+    with pytest.raises(na.NeedleHipError):
+        empty.search(base[0], 3)
+
+
+def test_near_duplicates_take_the_exact_list_scan(ctx, oracle):
+    rng = np.random.default_rng(9)
+    d = 32
+    base = rng.random((4000, d), dtype=F)
+    centre = rng.random(d, dtype=F)
+    base[1000:1200] = centre + (rng.standard_normal((200, d)) * 1e-7).astype(F)
+    cents = oracle.ivf_kmeans(base[:800], 8, max_iter=10, seed=2)
+    from needle_amd.ivf import IvfConfig, IvfIndex
+
+    ix = IvfIndex(d, IvfConfig.new(8).with_nprobe(3), ctx=ctx)
+    ix.set_centroids(cents)
+    ix.add(range(4000), base)
+    assign = oracle.ivf_assign(base, cents)
+    offsets, order = oracle.ivf_lists_from_assignment(assign, 8)
+    queries = np.stack([centre, rng.random(d, dtype=F)])
+    ctx.reset_metrics()
+    _check_search(oracle, ix, base, cents, offsets, order, queries, 3, 10)
+    assert ctx.metrics()["fallback_queries"] >= 1
+    _check_search(oracle, ix, base, cents, offsets, order, queries, 3, 10, precision="exact")
+    ix.close()
+
+
+def test_gpu_training_produces_usable_centroids(ctx, oracle):
+    from needle_amd.ivf import IvfConfig, IvfIndex
+
+    rng = np.random.default_rng(11)
+    blobs = np.concatenate([rng.normal(c, 0.05, size=(200, 8)) for c in (0.0, 1.0, 2.0, 3.0)]).astype(F)
+    ix = IvfIndex(8, IvfConfig.new(4).with_nprobe(1).with_max_iterations(20), ctx=ctx)
+    ix.train(blobs)
+    assert ix.is_trained() and ix.centroids.shape == (4, 8)
+    ix.add(range(800), blobs)
+    sizes = ix.cluster_sizes()
+    assert int(sizes.sum()) == 800  # ivf.rs:788-805
+    res = ix.search(blobs[5], 3)
+    assert res[0][0] == 5 and res[0][1] == 0.0
+    ix.close()
