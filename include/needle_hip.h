@@ -213,6 +213,19 @@ needle_hip_status needle_hip_ivf_list_sizes(const needle_hip_index* index, uint3
  * ivf.rs:509-567, with params->nprobe: the k nearest rows of the probed lists
  * by (distance, id). */
 
+/* ---- quantized (ADC) indexes ------------------------------------------- */
+
+/* A code matrix scored with ProductQuantizer::{compute_distance_table,
+ * distance_with_table}, src/indexing/quantization.rs:468-503: per query the
+ * [m][256] table of squared sub-distances, per row sqrt(sum_i table[i][code_i])
+ * in subspace order.  codes: n x m host bytes (ProductQuantizer::encode output,
+ * quantization.rs:377-398); codebooks: [m][256][dim/m] host f32
+ * (quantization.rs:322-323).  needle_hip_batch_search on this index returns the
+ * k rows nearest by that distance, ties to the lower row id (k <= 256). */
+needle_hip_status needle_hip_pq_build(needle_hip_ctx* ctx, const uint8_t* codes, uint64_t n, uint32_t dim,
+                                      uint32_t m, const float* codebooks, const uint32_t* valid_bitmask,
+                                      needle_hip_index** out);
+
 /* ---- operator-level calls --------------------------------------------- */
 
 /* GpuAccelerator::batch_{cosine,euclidean}_distance / batch_dot_product,

@@ -117,6 +117,12 @@ void nh::index_free(needle_hip_index* ix) {
     if (ix->d_list_pos) (void)hipFree(ix->d_list_pos);
     if (ix->d_list_len) (void)hipFree(ix->d_list_len);
     if (ix->d_pos2id) (void)hipFree(ix->d_pos2id);
+    if (ix->d_codes) (void)hipFree(ix->d_codes);
+    if (ix->d_codebooks) (void)hipFree(ix->d_codebooks);
+    if (ix->d_sq_min) (void)hipFree(ix->d_sq_min);
+    if (ix->d_sq_scale) (void)hipFree(ix->d_sq_scale);
+    if (ix->d_sq_inv) (void)hipFree(ix->d_sq_inv);
+    ix->w_scores.release();
     if (ix->d_op_f32 && !ix->op_f32_alias) (void)hipFree(ix->d_op_f32);
     if (ix->d_raw) (void)hipFree(ix->d_raw);
     if (ix->d_op_bf16) (void)hipFree(ix->d_op_bf16);
@@ -535,7 +541,11 @@ static needle_hip_status search_device_locked(needle_hip_index* ix, const float*
         const uint32_t QB = 16384;
         for (uint32_t q0 = 0; q0 < q; q0 += QB) {
             const uint32_t qb = std::min(QB, q - q0);
-            if (ix->kind == KIND_IVF)
+            if (ix->kind == KIND_PQ)
+                ST_TRY(pq_search_batch_device(ix, d_queries + (size_t)q0 * ix->dim, qb, k, d_filter,
+                                              d_out_ids + (size_t)q0 * k, d_out_dists + (size_t)q0 * k,
+                                              d_out_counts + q0));
+            else if (ix->kind == KIND_IVF)
                 ST_TRY(ivf_search_batch_device(ix, d_queries + (size_t)q0 * ix->dim, qb, k, params->nprobe, precision,
                                                d_filter, d_out_ids + (size_t)q0 * k, d_out_dists + (size_t)q0 * k,
                                                d_out_counts + q0));

@@ -1,0 +1,108 @@
+// Quantized (ADC) indexes behind the C ABI (include/needle_hip.h, "quantized (ADC) indexes").
+#include "nh_api.h"
+
+using namespace nh;
+
+extern "C" needle_hip_status needle_hip_pq_build(needle_hip_ctx* c, const uint8_t* codes, uint64_t n, uint32_t dim,
+                                                 uint32_t m, const float* codebooks, const uint32_t* valid_bitmask,
+                                                 needle_hip_index** out) {
+    if (!c || !out) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (dim == 0 || m == 0 || dim % m != 0 || !codebooks)
+        return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "need codebooks and dim (%u) divisible by the subvector count (%u)", dim, m);
+    if (pq_scan_queries_per_block(m) == 0)
+        return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "%u subvectors: the distance table does not fit on chip", m);
+    if (n > 0 && !codes) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "codes is null");
+    if (n >= 0xfffffff0ull) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "too many rows");
+    HIP_TRY(hipSetDevice(c->device));
+    needle_hip_index* ix = new (std::nothrow) needle_hip_index();
+    if (!ix) return fail(NEEDLE_HIP_ERR_OUT_OF_MEMORY, "host allocation failed");
+    ix->ctx = c;
+    ix->kind = KIND_PQ;
+    ix->n = n;
+    ix->dim = dim;
+    ix->n_pad = (uint32_t)n;
+    ix->metric = NEEDLE_METRIC_EUCLIDEAN;
+    ix->pq_m = m;
+    ix->pq_dsub = dim / m;
+    const size_t cb_bytes = (size_t)m * 256 * ix->pq_dsub * sizeof(float);
+    hipError_t e = hipMalloc((void**)&ix->d_codebooks, cb_bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(ix->d_codebooks, codebooks, cb_bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && n > 0) {
+        e = hipMalloc((void**)&ix->d_codes, (size_t)n * m + 16);
+        if (e == hipSuccess) e = hipMemcpyAsync(ix->d_codes, codes, (size_t)n * m, hipMemcpyHostToDevice, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    needle_hip_status st = NEEDLE_HIP_OK;
+    if (e != hipSuccess)
+        st = fail(e == hipErrorOutOfMemory ? NEEDLE_HIP_ERR_OUT_OF_MEMORY : NEEDLE_HIP_ERR_HIP, "HIP error %d (%s) uploading codes",
+                  (int)e, hipGetErrorString(e));
+    if (st == NEEDLE_HIP_OK) st = upload_mask(ix, valid_bitmask);
+    if (st != NEEDLE_HIP_OK) { index_free(ix); return st; }
+    *out = ix;
+    return NEEDLE_HIP_OK;
+}
+
+needle_hip_status nh::pq_search_batch_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k,
+                                             const uint32_t* d_filter, uint64_t* d_out_ids, float* d_out_dists,
+                                             uint32_t* d_out_counts) {
+    needle_hip_ctx* c = ix->ctx;
+    const uint32_t n = (uint32_t)ix->n;
+    if (k > KPRIME_MAX) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "k = %u exceeds %d for the quantized scans", k, KPRIME_MAX);
+    const uint32_t qg = pq_scan_queries_per_block(ix->pq_m);
+    const uint32_t groups = (q + qg - 1) / qg;
+    // slices of the code matrix: enough workgroups to fill the chip, slices of >= 4096 rows,
+    // and 4 * S lists of k entries per query must fit the merge kernel's LDS
+    uint32_t S = std::max<uint32_t>(1, (4u * (uint32_t)c->n_cu + groups - 1) / groups);
+    S = std::min<uint32_t>(S, std::max<uint32_t>(1, n / 4096));
+    S = std::min<uint32_t>(S, std::max<uint32_t>(1, 60000u / (4u * k * (uint32_t)sizeof(uint64_t))));
+    const uint32_t rows_per_split = (n + S - 1) / S;
+    S = (n + rows_per_split - 1) / rows_per_split;
+    const uint32_t lists_per_q = 4 * S, cap = 2 * k + 64;
+
+    HIP_TRY(ix->w_lists.ensure((size_t)q * lists_per_q * cap * sizeof(uint2)));
+    HIP_TRY(ix->w_lcnt.ensure((size_t)q * lists_per_q * sizeof(uint32_t)));
+    HIP_TRY(ix->w_cand.ensure((size_t)q * k * sizeof(uint32_t)));
+    HIP_TRY(ix->w_scores.ensure((size_t)q * k * sizeof(float)));
+    HIP_TRY(ix->w_candn.ensure((size_t)q * sizeof(uint32_t)));
+    HIP_TRY(ix->w_tau.ensure((size_t)q * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(ix->w_lcnt.p, 0, (size_t)q * lists_per_q * sizeof(uint32_t), c->stream));
+
+    PqScanParams sp{};
+    sp.codes = ix->d_codes;
+    sp.codebooks = ix->d_codebooks;
+    sp.queries = d_queries;
+    sp.valid = ix->d_valid;
+    sp.filter = d_filter;
+    sp.lists = ix->w_lists.as<uint2>();
+    sp.list_counts = ix->w_lcnt.as<uint32_t>();
+    sp.n = n; sp.m = ix->pq_m; sp.dsub = ix->pq_dsub; sp.dim = ix->dim; sp.q = q; sp.qg = qg;
+    sp.n_splits = S; sp.rows_per_split = rows_per_split; sp.k = k; sp.cap = cap;
+    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(launch_pq_scan(sp, c->stream));
+    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+
+    PostParams pp{};
+    pp.lists = sp.lists;
+    pp.list_counts = sp.list_counts;
+    pp.cand_ids = ix->w_cand.as<uint32_t>();
+    pp.cand_scores = ix->w_scores.as<float>();
+    pp.cand_n = ix->w_candn.as<uint32_t>();
+    pp.tau_star = ix->w_tau.as<float>();
+    pp.out_ids = d_out_ids;
+    pp.out_dists = d_out_dists;
+    pp.out_counts = d_out_counts;
+    pp.q = q; pp.n = n; pp.dim = ix->dim; pp.k = k; pp.kprime = k; pp.cap = cap; pp.n_splits = lists_per_q;
+    HIP_TRY(launch_merge_select(pp, c->stream));
+    HIP_TRY(launch_emit_sorted(pp, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->profiling) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        std::lock_guard<std::mutex> g(c->mu);
+        c->m.scan_launches += 1;
+        c->m.scan_ms_total += ms;
+        c->m.last_scan_ms = ms;
+    }
+    return NEEDLE_HIP_OK;
+}

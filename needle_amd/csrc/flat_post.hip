@@ -50,7 +50,11 @@ __global__ __launch_bounds__(64) void merge_select_kernel(PostParams p) {
     for (uint32_t i = 0; i < total; i += 64) {
         const bool keep = (i + lane < total) && (mkeys[i + lane] >= prefix);
         const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
-        if (keep) p.cand_ids[(uint64_t)q * p.kprime + base + __builtin_popcountll(m & lt_mask)] = ~(uint32_t)mkeys[i + lane];
+        if (keep) {
+            const uint64_t slot = (uint64_t)q * p.kprime + base + __builtin_popcountll(m & lt_mask);
+            p.cand_ids[slot] = ~(uint32_t)mkeys[i + lane];
+            if (p.cand_scores) p.cand_scores[slot] = ord2f((uint32_t)(mkeys[i + lane] >> 32));
+        }
         base += __builtin_popcountll(m);
     }
     if (lane == 0) {
@@ -162,6 +166,44 @@ hipError_t launch_rescore_finalize(const PostParams& p, hipStream_t stream) {
     if (p.q == 0) return hipSuccess;
     const uint32_t threads = ((p.kprime + 63) / 64) * 64;
     hipLaunchKernelGGL(rescore_finalize_kernel, dim3(p.q), dim3(threads), 0, stream, p);
+    return hipGetLastError();
+}
+
+// emit_sorted: the merged candidates already carry reference distances (score = -distance).
+__global__ __launch_bounds__(256) void emit_sorted_kernel(PostParams p) {
+    __shared__ uint64_t skey[KPRIME_MAX];
+    const uint32_t q = blockIdx.x, j = threadIdx.x;
+    const uint32_t nc = min(p.cand_n[q], p.kprime);
+    const uint32_t k_eff = min(p.k, nc);
+    uint64_t key = ~0ull;
+    float d = 0.0f;
+    uint32_t id = 0;
+    if (j < nc) {
+        id = p.cand_ids[(uint64_t)q * p.kprime + j];
+        d = canon_distance(-p.cand_scores[(uint64_t)q * p.kprime + j]);
+        key = hit_key(d, id);
+    }
+    if (j < KPRIME_MAX) skey[j] = key;
+    __syncthreads();
+    if (j < nc) {
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < nc; ++i) rank += (skey[i] < key) ? 1u : 0u;
+        if (rank < k_eff) {
+            p.out_ids[(uint64_t)q * p.k + rank] = id;
+            p.out_dists[(uint64_t)q * p.k + rank] = d;
+        }
+    }
+    for (uint32_t r = k_eff + j; r < p.k; r += blockDim.x) {
+        p.out_ids[(uint64_t)q * p.k + r] = ~0ull;
+        p.out_dists[(uint64_t)q * p.k + r] = INFINITY;
+    }
+    if (j == 0) p.out_counts[q] = k_eff;
+}
+
+hipError_t launch_emit_sorted(const PostParams& p, hipStream_t stream) {
+    if (p.q == 0) return hipSuccess;
+    const uint32_t threads = ((p.kprime + 63) / 64) * 64;
+    hipLaunchKernelGGL(emit_sorted_kernel, dim3(p.q), dim3(threads), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -65,7 +65,7 @@ struct needle_hip_ctx {
     nh::DevBuf scratch[4];  // operator-level calls
 };
 
-enum IndexKind { KIND_FLAT = 0, KIND_IVF = 1 };
+enum IndexKind { KIND_FLAT = 0, KIND_IVF = 1, KIND_PQ = 2, KIND_SQ8 = 3 };
 
 struct needle_hip_index {
     needle_hip_ctx* ctx = nullptr;
@@ -91,6 +91,15 @@ struct needle_hip_index {
     uint32_t* d_list_pos = nullptr;
     uint32_t* d_list_len = nullptr;
     uint32_t* d_pos2id = nullptr;  // [n_pad] row id of a position, ~0 for padding
+    // quantized code matrices
+    uint8_t* d_codes = nullptr;    // PQ: [n][pq_m]; SQ8: [n_pad][dpad_f32] zero padded
+    float* d_codebooks = nullptr;  // PQ: [pq_m][256][pq_dsub]
+    uint32_t pq_m = 0, pq_dsub = 0;
+    float* d_sq_min = nullptr;     // SQ8: [dim] min_vals
+    float* d_sq_scale = nullptr;   // SQ8: [dim] scale
+    float* d_sq_inv = nullptr;     // SQ8: [dpad] 1/scale, zero padded (first-pass query scaling)
+    double sq_min_norm = 0.0;      // SQ8: |min_vals|
+    nh::DevBuf w_scores;
     // per-search workspace (grow-only)
     nh::DevBuf w_qraw, w_qop, w_qn2, w_lists, w_lcnt, w_cand, w_candn, w_tau, w_flagged, w_flagcnt, w_filter, w_premax,
         w_tau0;
@@ -112,6 +121,10 @@ uint32_t choose_kprime(uint32_t k, int precision);
 void index_free(needle_hip_index* ix);
 needle_hip_status finish_operands(needle_hip_index* ix, bool validate);
 needle_hip_status upload_mask(needle_hip_index* ix, const uint32_t* mask_host);
+// quantized scans of one batch (api_adc.hip)
+needle_hip_status pq_search_batch_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k,
+                                         const uint32_t* d_filter, uint64_t* d_out_ids, float* d_out_dists,
+                                         uint32_t* d_out_counts);
 // IVF search of one batch (api_ivf.hip)
 needle_hip_status ivf_search_batch_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k,
                                           uint32_t nprobe, int precision, const uint32_t* d_filter,

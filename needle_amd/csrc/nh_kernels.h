@@ -35,6 +35,7 @@ struct PostParams {
     const uint32_t* list_counts;
     uint32_t* cand_ids;       // [q][kprime]
     uint32_t* cand_n;         // [q]
+    float* cand_scores;       // [q][kprime] first-pass scores of the kept candidates, or null
     float* tau_star;          // [q]
     const float* tau0;        // [q] threshold the main pass started from, or null
     const uint32_t* pos2id;   // candidates are positions of a list-ordered copy: their row ids, or null
@@ -49,6 +50,25 @@ struct PostParams {
 };
 hipError_t launch_merge_select(const PostParams& p, hipStream_t stream);
 hipError_t launch_rescore_finalize(const PostParams& p, hipStream_t stream);
+// For scans whose scores ARE the reference distances (score = -distance): rank the merged
+// candidates by (distance, id) and emit the k best.  Needs cand_scores.
+hipError_t launch_emit_sorted(const PostParams& p, hipStream_t stream);
+
+// ---- adc.hip ---------------------------------------------------------------
+// ProductQuantizer table scan, src/indexing/quantization.rs:468-503: per query the distance table
+// [m][256] is built in LDS, every row's distance is the table sum in subspace order, then sqrt.
+struct PqScanParams {
+    const uint8_t* codes;      // [n][m]
+    const float* codebooks;    // [m][256][dsub]
+    const float* queries;      // [q][dim] raw
+    const uint32_t* valid;
+    const uint32_t* filter;
+    uint2* lists;              // [q][n_splits * 4][cap]  (bits of -distance, row)
+    uint32_t* list_counts;     // [q][n_splits * 4]
+    uint32_t n, m, dsub, dim, q, qg, n_splits, rows_per_split, k, cap;
+};
+hipError_t launch_pq_scan(const PqScanParams& p, hipStream_t stream);
+uint32_t pq_scan_queries_per_block(uint32_t m);
 
 // Exact scan (every row scored in the reference's scalar order): the path for
 // queries whose first-pass candidates fail the bound check, for the metrics with
