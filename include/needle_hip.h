@@ -226,6 +226,16 @@ needle_hip_status needle_hip_pq_build(needle_hip_ctx* ctx, const uint8_t* codes,
                                       uint32_t m, const float* codebooks, const uint32_t* valid_bitmask,
                                       needle_hip_index** out);
 
+/* A u8 code matrix scored with ScalarQuantizer::asymmetric_distance,
+ * src/indexing/quantization.rs:277-285: sqrt(sum_j (q_j - (c_j / scale_j + min_j))^2).
+ * codes: n x dim host bytes (ScalarQuantizer::quantize output, :219-238);
+ * min_vals, scale: [dim] host f32 of the trained quantizer (:137-141).
+ * needle_hip_batch_search returns the k nearest rows by that distance, bit-equal
+ * to the reference arithmetic, ties to the lower row id. */
+needle_hip_status needle_hip_sq8_build(needle_hip_ctx* ctx, const uint8_t* codes, uint64_t n, uint32_t dim,
+                                       const float* min_vals, const float* scale,
+                                       const uint32_t* valid_bitmask, needle_hip_index** out);
+
 /* ---- operator-level calls --------------------------------------------- */
 
 /* GpuAccelerator::batch_{cosine,euclidean}_distance / batch_dot_product,

@@ -365,6 +365,9 @@ needle_hip_status nh::run_exact(needle_hip_index* ix, const float* d_queries, co
         p.prefix = ix->x_u64.as<uint64_t>();
         p.sel = ix->x_sel.as<uint64_t>();
         p.f = f; p.n = n; p.dim = ix->dim; p.k = k; p.metric = ix->metric; p.arith = ix->arith;
+        if (ix->kind == KIND_SQ8) {
+            p.sq_codes = ix->d_codes; p.sq_min = ix->d_sq_min; p.sq_scale = ix->d_sq_scale; p.sq_stride = ix->dpad_f32;
+        }
         if (ivf) {
             // rows a query may return = the rows of the lists it probes
             const uint32_t* sel = d_qsel ? d_qsel + f0 : nullptr;
@@ -402,8 +405,10 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     needle_hip_ctx* c = ix->ctx;
     const uint32_t n = (uint32_t)ix->n;
     const uint32_t kprime = choose_kprime(std::min(k, n), precision);
-    const bool exact_only = precision == NEEDLE_PRECISION_EXACT_SCAN || !metric_has_first_pass(ix->metric) ||
+    const bool sq8 = ix->kind == KIND_SQ8;
+    const bool exact_only = precision == NEEDLE_PRECISION_EXACT_SCAN || (!sq8 && !metric_has_first_pass(ix->metric)) ||
                             kprime > KPRIME_MAX;
+    if (sq8 && precision == NEEDLE_PRECISION_BF16) precision = NEEDLE_PRECISION_FP32;
     if (exact_only) {
         ST_TRY(run_exact(ix, d_queries, nullptr, q, k, d_filter, d_out_ids, d_out_dists, d_out_counts));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -441,13 +446,18 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     HIP_TRY(hipMemsetAsync(ix->w_qop.p, 0, (size_t)q_pad * dpad * elt, c->stream));
     HIP_TRY(hipMemsetAsync(ix->w_flagcnt.p, 0, sizeof(uint32_t), c->stream));
     const bool normalize = ix->metric == NEEDLE_METRIC_COSINE;
-    HIP_TRY(launch_row_prep(d_queries, q, ix->dim, dpad, normalize,
-                            precision == NEEDLE_PRECISION_BF16 ? nullptr : ix->w_qop.as<float>(),
-                            precision == NEEDLE_PRECISION_BF16 ? ix->w_qop.as<uint16_t>() : nullptr, nullptr, nullptr,
-                            ix->w_qn2.as<double>(), nullptr, c->stream));
+    if (sq8)
+        HIP_TRY(launch_sq8_query_prep(d_queries, q, ix->dim, dpad, ix->d_sq_min, ix->d_sq_scale, ix->w_qop.as<float>(),
+                                      ix->w_qn2.as<double>(), c->stream));
+    else
+        HIP_TRY(launch_row_prep(d_queries, q, ix->dim, dpad, normalize,
+                                precision == NEEDLE_PRECISION_BF16 ? nullptr : ix->w_qop.as<float>(),
+                                precision == NEEDLE_PRECISION_BF16 ? ix->w_qop.as<uint16_t>() : nullptr, nullptr, nullptr,
+                                ix->w_qn2.as<double>(), nullptr, c->stream));
 
     ScanParams sp{};
     sp.base_op = precision == NEEDLE_PRECISION_BF16 ? (const void*)ix->d_op_bf16 : (const void*)ix->d_op_f32;
+    if (sq8) { sp.base_op = ix->d_codes; sp.base_is_u8 = 1; }
     sp.query_op = ix->w_qop.p;
     sp.cinit = ix->d_cinit;
     sp.valid = ix->d_valid;
@@ -497,6 +507,10 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     pp.q = q; pp.n = n; pp.dim = ix->dim; pp.k = k; pp.kprime = kprime; pp.cap = cap; pp.n_splits = plan.n_splits;
     pp.metric = ix->metric; pp.arith = ix->arith; pp.precision = precision;
     pp.max_norm = ix->max_norm;
+    if (sq8) {
+        pp.sq_codes = ix->d_codes; pp.sq_min = ix->d_sq_min; pp.sq_scale = ix->d_sq_scale; pp.sq_stride = ix->dpad_f32;
+        pp.aux_norm = (float)(ix->sq_min_norm * (1.0 + 1e-6));
+    }
     HIP_TRY(launch_merge_select(pp, c->stream));
     HIP_TRY(launch_rescore_finalize(pp, c->stream));
 

@@ -106,3 +106,67 @@ needle_hip_status nh::pq_search_batch_device(needle_hip_index* ix, const float* 
     }
     return NEEDLE_HIP_OK;
 }
+
+// ---------------------------------------------------------------------------
+// scalar-quantized code matrix
+// ---------------------------------------------------------------------------
+extern "C" needle_hip_status needle_hip_sq8_build(needle_hip_ctx* c, const uint8_t* codes, uint64_t n, uint32_t dim,
+                                                  const float* min_vals, const float* scale,
+                                                  const uint32_t* valid_bitmask, needle_hip_index** out) {
+    if (!c || !out) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (dim == 0 || !min_vals || !scale) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "need min_vals and scale of a trained quantizer");
+    if (n > 0 && !codes) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "codes is null");
+    if (n >= 0xfffffff0ull - TILE_ROWS) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "too many rows");
+    double mn2 = 0.0;
+    for (uint32_t j = 0; j < dim; ++j) {
+        if (!std::isfinite(min_vals[j]) || !std::isfinite(scale[j]) || scale[j] == 0.0f)
+            return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "quantizer parameter %u is not finite / zero scale", j);
+        mn2 += (double)min_vals[j] * (double)min_vals[j];
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    needle_hip_index* ix = new (std::nothrow) needle_hip_index();
+    if (!ix) return fail(NEEDLE_HIP_ERR_OUT_OF_MEMORY, "host allocation failed");
+    ix->ctx = c;
+    ix->kind = KIND_SQ8;
+    ix->n = n;
+    ix->dim = dim;
+    ix->n_pad = round_up((uint32_t)n, TILE_ROWS);
+    ix->metric = NEEDLE_METRIC_EUCLIDEAN;
+    ix->arith = NEEDLE_ARITH_DISTANCE_RS;
+    ix->dpad_f32 = round_up(dim, flat_scan_kstep(NEEDLE_PRECISION_FP32));
+    ix->sq_min_norm = std::sqrt(mn2);
+    uint32_t* d_bits = nullptr;
+    hipError_t e = hipMalloc((void**)&ix->d_sq_min, sizeof(float) * dim);
+    if (e == hipSuccess) e = hipMalloc((void**)&ix->d_sq_scale, sizeof(float) * dim);
+    if (e == hipSuccess) e = hipMemcpyAsync(ix->d_sq_min, min_vals, sizeof(float) * dim, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ix->d_sq_scale, scale, sizeof(float) * dim, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && n > 0) {
+        const size_t bytes = (size_t)ix->n_pad * ix->dpad_f32;
+        e = hipMalloc((void**)&ix->d_codes, bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(ix->d_codes, 0, bytes, c->stream);
+        if (e == hipSuccess)
+            e = hipMemcpy2DAsync(ix->d_codes, ix->dpad_f32, codes, dim, dim, n, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMalloc((void**)&ix->d_cinit, sizeof(float) * ix->n_pad);
+        if (e == hipSuccess) e = hipMemsetAsync(ix->d_cinit, 0, sizeof(float) * ix->n_pad, c->stream);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_bits, sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(d_bits, 0, sizeof(uint32_t), c->stream);
+        if (e == hipSuccess)
+            e = launch_sq8_row_prep(ix->d_codes, n, dim, ix->dpad_f32, ix->d_sq_min, ix->d_sq_scale, ix->d_cinit, d_bits,
+                                    c->stream);
+        uint32_t bits = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&bits, d_bits, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        memcpy(&ix->max_norm, &bits, sizeof(float));
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (d_bits) (void)hipFree(d_bits);
+    needle_hip_status st = NEEDLE_HIP_OK;
+    if (e != hipSuccess)
+        st = fail(e == hipErrorOutOfMemory ? NEEDLE_HIP_ERR_OUT_OF_MEMORY : NEEDLE_HIP_ERR_HIP, "HIP error %d (%s) uploading codes",
+                  (int)e, hipGetErrorString(e));
+    if (st == NEEDLE_HIP_OK) st = upload_mask(ix, valid_bitmask);
+    if (st != NEEDLE_HIP_OK) { index_free(ix); return st; }
+    *out = ix;
+    return NEEDLE_HIP_OK;
+}

@@ -120,6 +120,28 @@ __device__ inline bool bound_check(int metric, int precision, float tau, float d
     }
 }
 
+// Scalar-quantized rows: score = sum_j (q_j/scale_j) c_j - |v|^2/2 with v = decoded row, so the
+// squared distance is qconst - 2*score, qconst = sum_j (q_j^2 - 2 q_j min_j).  vmax = max |v|,
+// mnorm = |min_vals|.  Both the first-pass score and the reference's own value (decode, subtract,
+// square, sequential sum) err by at most gam * (|q| + |v| + |min|)^2-sized terms.
+__device__ inline bool bound_check_sq8(float tau, float dk, double qconst, double vmax, double mnorm, uint32_t dim) {
+    if (tau == -INFINITY) return true;
+    if (!(dk == dk) || !(tau == tau)) return false;
+    const double u = 5.9604644775390625e-08;
+    const double gam = 2.0 * ((double)dim + 16.0) * u;
+    // |q| <= sqrt(|qconst| + 2|q||min|): bound |q| through qconst = |q|^2 - 2 q.min  ->  |q| <= |min| + sqrt(|min|^2 + |qconst|)
+    const double qn = mnorm + sqrt(mnorm * mnorm + fabs(qconst));
+    if (!(qn < 1e17) || !(vmax < 1e17)) return false;
+    const double eps_s = gam * (qn * (vmax + mnorm) + 0.5 * vmax * vmax);
+    const double lb2 = qconst - 2.0 * (double)tau - 2.0 * eps_s;
+    if (!(lb2 > 0.0)) return false;
+    const double lb = sqrt(lb2);
+    const double e_ref = gam * (lb + 2.0 * vmax + mnorm) * (lb + 2.0 * vmax + mnorm);
+    const double lb2r = lb2 - e_ref;
+    if (!(lb2r > 0.0)) return false;
+    return sqrt(lb2r) * (1.0 - gam) > (double)dk;
+}
+
 // ---------------------------------------------------------------------------
 // rescore_finalize: one workgroup per query, one thread per candidate.
 // Reference-order distance of every candidate, rank by (distance, id), emit the
@@ -137,8 +159,12 @@ __global__ __launch_bounds__(256) void rescore_finalize_kernel(PostParams p) {
     if (j < nc) {
         const uint32_t pos = p.cand_ids[(uint64_t)q * p.kprime + j];
         id = p.pos2id ? p.pos2id[pos] : pos;
-        d = canon_distance(exact_distance(p.metric, p.arith, p.query_raw + (uint64_t)q * p.dim,
-                                          p.base_raw + (uint64_t)pos * p.dim, p.dim));
+        if (p.sq_codes)
+            d = canon_distance(exact_sq8(p.query_raw + (uint64_t)q * p.dim, p.sq_codes + (uint64_t)pos * p.sq_stride,
+                                         p.sq_min, p.sq_scale, p.dim));
+        else
+            d = canon_distance(exact_distance(p.metric, p.arith, p.query_raw + (uint64_t)q * p.dim,
+                                              p.base_raw + (uint64_t)pos * p.dim, p.dim));
         key = hit_key(d, id);
     }
     if (j < KPRIME_MAX) { skey[j] = key; sdist[j] = d; }
@@ -151,7 +177,9 @@ __global__ __launch_bounds__(256) void rescore_finalize_kernel(PostParams p) {
             p.out_dists[(uint64_t)q * p.k + rank] = d;
         }
         if (rank + 1 == k_eff) {
-            const bool ok = bound_check(p.metric, p.precision, p.tau_star[q], d, p.qnorm2[q], (double)p.max_norm, p.dim);
+            const bool ok = p.sq_codes
+                                ? bound_check_sq8(p.tau_star[q], d, p.qnorm2[q], (double)p.max_norm, (double)p.aux_norm, p.dim)
+                                : bound_check(p.metric, p.precision, p.tau_star[q], d, p.qnorm2[q], (double)p.max_norm, p.dim);
             if (!ok) p.flagged[atomicAdd(p.flag_count, 1u)] = q;
         }
     }
@@ -224,9 +252,14 @@ __global__ __launch_bounds__(256) void exact_keys_kernel(ExactParams p) {
     if (live && p.filter) live = bit_set(p.filter, id);
     uint64_t key = ~0ull;
     if (live) {
-        const float d = canon_distance(exact_distance(p.metric, p.arith, p.query_raw + (uint64_t)q * p.dim,
-                                                      p.base_raw + (uint64_t)i * p.dim, p.dim));
-        key = hit_key(d, id);
+        float d;
+        if (p.sq_codes)
+            d = exact_sq8(p.query_raw + (uint64_t)q * p.dim, p.sq_codes + (uint64_t)i * p.sq_stride, p.sq_min, p.sq_scale,
+                          p.dim);
+        else
+            d = exact_distance(p.metric, p.arith, p.query_raw + (uint64_t)q * p.dim, p.base_raw + (uint64_t)i * p.dim,
+                               p.dim);
+        key = hit_key(canon_distance(d), id);
     }
     if (i < p.n) p.keys[(uint64_t)f * p.n + i] = key;
     const uint64_t m = __builtin_amdgcn_ballot_w64(live);

@@ -94,7 +94,8 @@ __device__ inline void push_tile(const f32x16& acc, uint32_t row_base, uint32_t 
 constexpr int F32_BK = 32;  // k-step staged per LDS buffer
 constexpr int F32_LD = 36;  // padded LDS row stride (floats): conflict-free ds_read_b128
 
-template <int MODE>
+// A_U8: the row operand is a u8 code matrix ([n_pad][dpad] bytes), widened to f32 while staging.
+template <int MODE, bool A_U8 = false>
 __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
     // [A buf0][A buf1][B buf0][B buf1], each 128 rows x 36 floats
     __shared__ __attribute__((aligned(16))) float smem[4 * TILE_ROWS * F32_LD];
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
     const uint32_t KC = p.dpad / F32_BK;
     const uint32_t total = (t1 > t0 ? (t1 - t0) : 0) * KC;
     const float* __restrict__ gA = (const float*)p.base_op;
+    const uint8_t* __restrict__ gA8 = (const uint8_t*)p.base_op;
     const float* __restrict__ gB = (const float*)p.query_op;
 
     f32x4 ra[4], rb[4];
@@ -160,7 +162,12 @@ __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t idx = tid + i * 256, r = idx >> 3, c4 = idx & 7;
-            ra[i] = *(const f32x4*)(gA + (uint64_t)(tile * TILE_ROWS + r) * p.dpad + kc * F32_BK + c4 * 4);
+            if (A_U8) {
+                const uint32_t w = *(const uint32_t*)(gA8 + (uint64_t)(tile * TILE_ROWS + r) * p.dpad + kc * F32_BK + c4 * 4);
+                ra[i] = f32x4{(float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u), (float)(w >> 24)};
+            } else {
+                ra[i] = *(const f32x4*)(gA + (uint64_t)(tile * TILE_ROWS + r) * p.dpad + kc * F32_BK + c4 * 4);
+            }
             if (MODE == MODE_IVF && qrow[i] == 0xffffffffu) {
                 rb[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             } else {
@@ -287,7 +294,8 @@ hipError_t launch_flat_scan(int precision, const ScanParams& p, hipStream_t stre
     const uint32_t grid = p.n_splits * p.q_tiles;
     if (grid == 0) return hipSuccess;
     if (precision == NEEDLE_PRECISION_FP32) {
-        hipLaunchKernelGGL(flat_scan_f32_kernel<MODE_FLAT>, dim3(grid), dim3(256), 0, stream, p);
+        if (p.base_is_u8) hipLaunchKernelGGL((flat_scan_f32_kernel<MODE_FLAT, true>), dim3(grid), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(flat_scan_f32_kernel<MODE_FLAT>, dim3(grid), dim3(256), 0, stream, p);
     } else {
         return hipErrorInvalidValue;
     }
@@ -298,7 +306,8 @@ hipError_t launch_flat_prepass(int precision, const ScanParams& p, float* d_tau0
     const uint32_t grid = p.n_splits * p.q_tiles;
     if (grid == 0) return hipSuccess;
     if (precision == NEEDLE_PRECISION_FP32) {
-        hipLaunchKernelGGL(flat_scan_f32_kernel<MODE_PRE>, dim3(grid), dim3(256), 0, stream, p);
+        if (p.base_is_u8) hipLaunchKernelGGL((flat_scan_f32_kernel<MODE_PRE, true>), dim3(grid), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(flat_scan_f32_kernel<MODE_PRE>, dim3(grid), dim3(256), 0, stream, p);
     } else {
         return hipErrorInvalidValue;
     }

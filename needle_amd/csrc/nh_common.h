@@ -93,6 +93,7 @@ struct ScanParams {
     const uint2* item_queries;  // (query index, probe slot) per item entry
     const uint32_t* pos2id;   // [n_pad] original row id of a position, ~0 for padding
     uint32_t nprobe;          // candidate list of (query, slot) is lists[(query * nprobe + slot) * cap]
+    uint32_t base_is_u8;      // base_op is a u8 code matrix (scalar-quantized scan)
 };
 
 }  // namespace nh

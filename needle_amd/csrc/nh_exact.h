@@ -115,6 +115,20 @@ __device__ inline float exact_chunk4(int metric, const float* __restrict__ q,
     }
 }
 
+// ScalarQuantizer::asymmetric_distance, src/indexing/quantization.rs:277-285:
+// decoded = (c as f32 / scale[i]) + min[i]; sum (from +0.0) of (q - decoded)^2; sqrt.
+__device__ inline float exact_sq8(const float* __restrict__ q, const uint8_t* __restrict__ codes,
+                                  const float* __restrict__ mins, const float* __restrict__ scale, uint32_t dim) {
+    float sum = 0.0f;
+    for (uint32_t i = 0; i < dim; ++i) {
+        const float dec = ((float)codes[i] / scale[i]) + mins[i];
+        const float diff = q[i] - dec;
+        const float sq = diff * diff;
+        sum = sum + sq;
+    }
+    return sqrtf(sum);
+}
+
 __device__ inline float exact_distance(int metric, int arith, const float* __restrict__ q,
                                        const float* __restrict__ b, uint32_t dim) {
     return arith == NEEDLE_ARITH_ACCEL_CHUNK4 ? exact_chunk4(metric, q, b, dim)

@@ -26,6 +26,13 @@ hipError_t launch_row_prep(const float* d_rows, uint64_t n, uint32_t dim, uint32
 hipError_t launch_validate_rows(const float* d_rows, uint64_t n, uint32_t dim, uint32_t* d_bad_row_plus1,
                                 hipStream_t stream);
 
+// Scalar-quantized index build: per row -|v|^2/2 (v = decoded row) and the running max |v|.
+hipError_t launch_sq8_row_prep(const uint8_t* d_codes, uint64_t n, uint32_t dim, uint32_t stride, const float* d_min,
+                               const float* d_scale, float* d_cinit, uint32_t* d_max_norm_bits, hipStream_t stream);
+// Scalar-quantized query upload: q_op = q / scale (zero padded to dpad), qconst = sum(q^2 - 2 q min).
+hipError_t launch_sq8_query_prep(const float* d_queries, uint32_t q, uint32_t dim, uint32_t dpad, const float* d_min,
+                                 const float* d_scale, float* d_qop, double* d_qconst, hipStream_t stream);
+
 // ---- flat_post.hip ---------------------------------------------------------
 struct PostParams {
     const float* base_raw;    // [n][dim] original rows
@@ -39,6 +46,12 @@ struct PostParams {
     float* tau_star;          // [q]
     const float* tau0;        // [q] threshold the main pass started from, or null
     const uint32_t* pos2id;   // candidates are positions of a list-ordered copy: their row ids, or null
+    // scalar-quantized rows: distances are ScalarQuantizer::asymmetric_distance on the codes
+    const uint8_t* sq_codes;  // [n_pad][sq_stride] or null
+    const float* sq_min;      // [dim]
+    const float* sq_scale;    // [dim]
+    uint32_t sq_stride;
+    float aux_norm;           // SQ8: |min_vals| (bound check)
     uint32_t* flagged;        // [q] query indices failing the bound check
     uint32_t* flag_count;     // [1]
     uint64_t* out_ids;        // [q][k]
@@ -81,6 +94,10 @@ struct ExactParams {
     const uint32_t* filter;
     const uint32_t* pos2id;   // rows are positions of a list-ordered copy: their row ids (~0 padding), or null
     const uint32_t* pos_filter;  // [f][pos_filter_words] per-slot bitmask over positions, or null
+    const uint8_t* sq_codes;  // scalar-quantized rows (see PostParams) or null
+    const float* sq_min;
+    const float* sq_scale;
+    uint32_t sq_stride;
     uint32_t pos_filter_words;
     uint64_t* keys;           // [f][n] workspace
     uint32_t* live;           // [f]

@@ -67,6 +67,63 @@ __global__ __launch_bounds__(256) void validate_rows_kernel(const float* __restr
     }
 }
 
+// ---- scalar-quantized operands --------------------------------------------
+// v = (c / scale) + min in f32 exactly as ScalarQuantizer::dequantize, src/indexing/quantization.rs:254-260
+__global__ __launch_bounds__(256) void sq8_row_prep_kernel(const uint8_t* __restrict__ codes, uint64_t n, uint32_t dim,
+                                                           uint32_t stride, const float* __restrict__ mins,
+                                                           const float* __restrict__ scale, float* __restrict__ cinit,
+                                                           uint32_t* __restrict__ max_norm_bits) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t row = (uint64_t)blockIdx.x * 4 + wave;
+    if (row >= n) return;
+    const uint8_t* c = codes + row * stride;
+    double s = 0.0;
+    for (uint32_t i = lane; i < dim; i += 64) {
+        const float v = ((float)c[i] / scale[i]) + mins[i];
+        s += (double)v * (double)v;
+    }
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) {
+        cinit[row] = -(float)(0.5 * s);
+        const float norm = (float)sqrt(s);
+        atomicMax(max_norm_bits, __float_as_uint(norm) + 1u);
+    }
+}
+
+hipError_t launch_sq8_row_prep(const uint8_t* d_codes, uint64_t n, uint32_t dim, uint32_t stride, const float* d_min,
+                               const float* d_scale, float* d_cinit, uint32_t* d_max_norm_bits, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(sq8_row_prep_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, stream, d_codes, n, dim, stride,
+                       d_min, d_scale, d_cinit, d_max_norm_bits);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void sq8_query_prep_kernel(const float* __restrict__ queries, uint32_t q, uint32_t dim,
+                                                             uint32_t dpad, const float* __restrict__ mins,
+                                                             const float* __restrict__ scale, float* __restrict__ qop,
+                                                             double* __restrict__ qconst) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t row = blockIdx.x * 4 + wave;
+    if (row >= q) return;
+    const float* src = queries + (uint64_t)row * dim;
+    double s = 0.0;
+    for (uint32_t i = lane; i < dim; i += 64) {
+        const float x = src[i];
+        qop[(uint64_t)row * dpad + i] = x / scale[i];
+        s += (double)x * (double)x - 2.0 * (double)x * (double)mins[i];
+    }
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) qconst[row] = s;
+}
+
+hipError_t launch_sq8_query_prep(const float* d_queries, uint32_t q, uint32_t dim, uint32_t dpad, const float* d_min,
+                                 const float* d_scale, float* d_qop, double* d_qconst, hipStream_t stream) {
+    if (q == 0) return hipSuccess;
+    hipLaunchKernelGGL(sq8_query_prep_kernel, dim3((q + 3) / 4), dim3(256), 0, stream, d_queries, q, dim, dpad, d_min,
+                       d_scale, d_qop, d_qconst);
+    return hipGetLastError();
+}
+
 hipError_t launch_validate_rows(const float* d_rows, uint64_t n, uint32_t dim, uint32_t* d_bad_row,
                                 hipStream_t stream) {
     hipError_t e = hipMemsetAsync(d_bad_row, 0xff, sizeof(uint32_t), stream);

@@ -174,3 +174,18 @@ class PqIndex(_CodeIndex):
         _lib.check(_lib.lib().needle_hip_pq_build(ctx._h, c.ctypes.data if self.n else None, self.n, pq.dimensions,
                                                   pq.num_subvectors, cb.ctypes.data,
                                                   vm.ctypes.data if vm is not None else None, C.byref(self._h)))
+
+
+class Sq8Index(_CodeIndex):
+    """Resident u8 code matrix scanned with ScalarQuantizer::asymmetric_distance."""
+
+    def __init__(self, ctx: Context, sq: ScalarQuantizer, codes, valid=None):
+        super().__init__()
+        c = np.ascontiguousarray(codes, dtype=np.uint8)
+        if c.ndim != 2 or c.shape[1] != sq.dimensions:
+            raise ValueError("codes must be [n, dimensions]")
+        self.ctx, self.sq, self.n = ctx, sq, c.shape[0]
+        vm = _mask_words(valid, self.n)
+        _lib.check(_lib.lib().needle_hip_sq8_build(ctx._h, c.ctypes.data if self.n else None, self.n, sq.dimensions,
+                                                   sq.min_vals.ctypes.data, sq.scale.ctypes.data,
+                                                   vm.ctypes.data if vm is not None else None, C.byref(self._h)))

@@ -74,3 +74,46 @@ def test_pq_masks_ties_and_edges(ctx, oracle):
     small = PqIndex(ctx, ProductQuantizer(opq.codebooks), codes[:5])
     _cmp(small.search(queries, 10), opq.batch_search(queries, codes[:5], 10))  # k > n
     small.close()
+
+
+@pytest.mark.parametrize("shape", [(6000, 32, 10), (30000, 100, 10), (20000, 384, 10), (900, 7, 3)])
+def test_sq8_asymmetric_scan(ctx, oracle, shape):
+    from needle_amd.quantization import ScalarQuantizer, Sq8Index
+
+    n, dim, k = shape
+    rng = np.random.default_rng(n + dim)
+    base = rng.standard_normal((n, dim)).astype(F)
+    osq = oracle.ScalarQuantizer.train(base[: max(50, n // 10)])
+    sq = ScalarQuantizer.train(base[: max(50, n // 10)])
+    assert np.array_equal(sq.min_vals, osq.min_vals) and np.array_equal(sq.scale, osq.scale)
+    codes = osq.quantize(base)
+    assert np.array_equal(sq.quantize(base[:500]), codes[:500])  # incl. clamping of out-of-range values
+    queries = rng.standard_normal((41, dim)).astype(F)
+    ix = Sq8Index(ctx, sq, codes)
+    _cmp(ix.search(queries, k), osq.batch_search(queries, codes, k))
+    _cmp(ix.search(queries[:5], k, precision="exact"), osq.batch_search(queries[:5], codes, k))
+    ix.close()
+
+
+def test_sq8_masks_duplicates_and_constant_dims(ctx, oracle):
+    from needle_amd.quantization import ScalarQuantizer, Sq8Index
+
+    rng = np.random.default_rng(8)
+    n, dim = 8000, 24
+    base = rng.random((n, dim), dtype=F)
+    base[:, 5] = 0.25  # constant dimension: scale falls back to 1.0 (quantization.rs:1125-1136)
+    osq = oracle.ScalarQuantizer.train(base)
+    assert osq.scale[5] == 1.0
+    codes = osq.quantize(base)
+    codes[3000:3300] = codes[11]  # identical codes: more ties than the first pass keeps -> exact scan
+    queries = rng.random((6, dim), dtype=F)
+    queries[0] = base[11]
+    valid = rng.random(n) > 0.3
+    sq = ScalarQuantizer(osq.min_vals, osq.max_vals, osq.scale)
+    ix = Sq8Index(ctx, sq, codes, valid=valid)
+    ctx.reset_metrics()
+    _cmp(ix.search(queries, 10), osq.batch_search(queries, codes, 10, valid=valid))
+    assert ctx.metrics()["fallback_queries"] >= 1
+    filt = (np.arange(n) % 7) == 0
+    _cmp(ix.search(queries, 10, filter_mask=filt), osq.batch_search(queries, codes, 10, valid=valid & filt))
+    ix.close()
