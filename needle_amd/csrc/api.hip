@@ -315,10 +315,10 @@ struct SplitPlan { uint32_t n_splits, tiles_per_split, xcd_map; };
 // Slices of the base per query block.  Workgroups = q_tiles * n_splits should
 // fill the chip in whole rounds; a multiple of 8 slices lets each XCD keep its
 // own slices in its L2 while its 32 CUs sweep them with different query blocks.
-static SplitPlan plan_splits(uint32_t q_tiles, uint32_t n_tiles, uint32_t slots) {
+static SplitPlan plan_splits(uint32_t q_tiles, uint32_t n_tiles, uint32_t slots, uint32_t max_splits) {
     SplitPlan best{1, n_tiles, 0};
     double best_score = -1.0;
-    const uint32_t s_max = std::min<uint32_t>(n_tiles, 64);
+    const uint32_t s_max = std::min<uint32_t>(n_tiles, std::min<uint32_t>(64, max_splits));
     for (uint32_t s = 1; s <= s_max; ++s) {
         const uint32_t tps = (n_tiles + s - 1) / s;
         const uint32_t s_eff = (n_tiles + tps - 1) / tps;
@@ -393,9 +393,22 @@ needle_hip_status nh::run_exact(needle_hip_index* ix, const float* d_queries, co
     return NEEDLE_HIP_OK;
 }
 
+// The bf16 operand copy is built on the first bf16 search of an index (callers hold ix->mu).
 static needle_hip_status ensure_bf16_copy(needle_hip_index* ix) {
     if (ix->d_op_bf16) return NEEDLE_HIP_OK;
-    return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "bf16 first pass is not built into this library version");
+    needle_hip_ctx* c = ix->ctx;
+    ix->dpad_bf16 = flat_scan_bf16_dpad(ix->dim);
+    const size_t bytes = (size_t)ix->n_pad * ix->dpad_bf16 * sizeof(uint16_t);
+    uint16_t* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, bytes));
+    hipError_t e = hipMemsetAsync(d, 0, bytes, c->stream);
+    if (e == hipSuccess)
+        e = launch_row_prep(ix->d_raw, ix->n, ix->dim, ix->dpad_bf16, ix->metric == NEEDLE_METRIC_COSINE, nullptr, d,
+                            nullptr, nullptr, nullptr, nullptr, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipFree(d); HIP_TRY(e); }
+    ix->d_op_bf16 = d;
+    return NEEDLE_HIP_OK;
 }
 
 // Device-resident search of one batch of at most QB queries.
@@ -404,11 +417,14 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
                                                float* d_out_dists, uint32_t* d_out_counts) {
     needle_hip_ctx* c = ix->ctx;
     const uint32_t n = (uint32_t)ix->n;
-    const uint32_t kprime = choose_kprime(std::min(k, n), precision);
     const bool sq8 = ix->kind == KIND_SQ8;
+    // bf16 is a hint: code matrices and dimensions beyond the register-resident query block use fp32
+    if (precision == NEEDLE_PRECISION_BF16 && (sq8 || flat_scan_bf16_dpad(ix->dim) == 0)) precision = NEEDLE_PRECISION_FP32;
+    if (precision == NEEDLE_PRECISION_BF16 && choose_kprime(std::min(k, n), precision) > KPRIME_MAX)
+        precision = NEEDLE_PRECISION_FP32;
+    const uint32_t kprime = choose_kprime(std::min(k, n), precision);
     const bool exact_only = precision == NEEDLE_PRECISION_EXACT_SCAN || (!sq8 && !metric_has_first_pass(ix->metric)) ||
                             kprime > KPRIME_MAX;
-    if (sq8 && precision == NEEDLE_PRECISION_BF16) precision = NEEDLE_PRECISION_FP32;
     if (exact_only) {
         ST_TRY(run_exact(ix, d_queries, nullptr, q, k, d_filter, d_out_ids, d_out_dists, d_out_counts));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -416,27 +432,33 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
         c->m.fallback_queries += q;
         return NEEDLE_HIP_OK;
     }
-    if (precision == NEEDLE_PRECISION_BF16) ST_TRY(ensure_bf16_copy(ix));
+    const bool bf16 = precision == NEEDLE_PRECISION_BF16;
+    if (bf16) ST_TRY(ensure_bf16_copy(ix));
 
-    const uint32_t q_pad = round_up(q, TILE_QUERIES), q_tiles = q_pad / TILE_QUERIES;
+    const uint32_t dpad = bf16 ? ix->dpad_bf16 : ix->dpad_f32;
+    const uint32_t q_block = flat_scan_queries_per_block(precision, dpad);
+    const uint32_t q_pad = round_up(q, q_block), q_tiles = q_pad / q_block;
     const uint32_t n_tiles = ix->n_pad / TILE_ROWS;
-    const uint32_t dpad = precision == NEEDLE_PRECISION_BF16 ? ix->dpad_bf16 : ix->dpad_f32;
     const uint32_t cap = list_cap(kprime);
-    SplitPlan plan = plan_splits(q_tiles, n_tiles, (uint32_t)c->n_cu * (uint32_t)flat_scan_blocks_per_cu(precision));
+    const uint32_t lists_per_split = bf16 ? 2 : 1;  // bf16: one list per lane half
+    // the merge holds a query's lists in LDS: lists * kprime keys of 8 bytes within 64 KB
+    const uint32_t max_splits = std::max<uint32_t>(1, 8192u / (kprime * lists_per_split));
+    SplitPlan plan = plan_splits(q_tiles, n_tiles, (uint32_t)c->n_cu * (uint32_t)flat_scan_blocks_per_cu(precision), max_splits);
     if (const char* ds = getenv("NEEDLE_HIP_DEBUG_SPLITS")) {  // development override, applied before any sizing
         const uint32_t s = (uint32_t)atoi(ds);
-        if (s >= 1 && s <= n_tiles && s <= 64) {
+        if (s >= 1 && s <= n_tiles && s <= 64 && s <= max_splits) {
             plan.tiles_per_split = (n_tiles + s - 1) / s;
             plan.n_splits = (n_tiles + plan.tiles_per_split - 1) / plan.tiles_per_split;
             plan.xcd_map = (plan.n_splits % 8 == 0) ? 1u : 0u;
         }
     }
-    const size_t elt = precision == NEEDLE_PRECISION_BF16 ? 2 : 4;
+    const size_t elt = bf16 ? 2 : 4;
+    const uint32_t n_lists = plan.n_splits * lists_per_split;  // per query
 
     HIP_TRY(ix->w_qop.ensure((size_t)q_pad * dpad * elt));
     HIP_TRY(ix->w_qn2.ensure((size_t)q_pad * sizeof(double)));
-    HIP_TRY(ix->w_lists.ensure((size_t)q_pad * plan.n_splits * cap * sizeof(uint2)));
-    HIP_TRY(ix->w_lcnt.ensure((size_t)q_pad * plan.n_splits * sizeof(uint32_t)));
+    HIP_TRY(ix->w_lists.ensure((size_t)q_pad * n_lists * cap * sizeof(uint2)));
+    HIP_TRY(ix->w_lcnt.ensure((size_t)q_pad * n_lists * sizeof(uint32_t)));
     HIP_TRY(ix->w_cand.ensure((size_t)q * kprime * sizeof(uint32_t)));
     HIP_TRY(ix->w_candn.ensure((size_t)q * sizeof(uint32_t)));
     HIP_TRY(ix->w_tau.ensure((size_t)q * sizeof(float)));
@@ -469,13 +491,20 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     sp.tiles_per_split = plan.tiles_per_split;
     sp.n_splits = plan.n_splits;
     sp.q_tiles = q_tiles;
+    sp.n_queries = q;
     sp.dpad = dpad;
     sp.kprime = kprime;
     sp.cap = cap;
     sp.xcd_map = plan.xcd_map;
     if (const char* dbg = getenv("NEEDLE_HIP_DEBUG")) sp.debug = (uint32_t)atoi(dbg);
     // threshold seeding: worth it once a slice is much longer than the sample
-    const uint32_t pre_tiles = std::min<uint32_t>(8, plan.tiles_per_split / 8);
+    uint32_t pre_tiles = std::min<uint32_t>(8, plan.tiles_per_split / 8);
+    // The seeded threshold is the kseed-th largest sampled group maximum: at least kseed >= k live rows
+    // exceed it, and the lower it ranks the fewer rows the main pass lists.  The bound check decides
+    // afterwards whether the candidates it leaves are enough.
+    sp.kseed = std::min<uint32_t>(kprime, std::min(k, n) + 6);
+    if (const char* e = getenv("NEEDLE_HIP_DEBUG_PRE")) pre_tiles = std::min<uint32_t>((uint32_t)atoi(e), plan.tiles_per_split);
+    if (const char* e = getenv("NEEDLE_HIP_DEBUG_KSEED")) sp.kseed = std::min<uint32_t>(std::max<uint32_t>((uint32_t)atoi(e), std::min(k, n)), kprime);
     const bool seeded = pre_tiles >= 1 && !(sp.debug & 2u);
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (seeded) {
@@ -488,6 +517,15 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     }
     HIP_TRY(launch_flat_scan(precision, sp, c->stream));
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    if (sp.debug & 8u) {  // development: how many candidates did the first pass list?
+        std::vector<uint32_t> lc((size_t)q_pad * n_lists);
+        HIP_TRY(hipMemcpyAsync(lc.data(), sp.list_counts, lc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        uint64_t tot = 0; uint32_t mx = 0;
+        for (size_t i = 0; i < (size_t)q * n_lists; ++i) { tot += lc[i]; mx = std::max(mx, lc[i]); }
+        fprintf(stderr, "[needle_hip] listed candidates: %.1f per query, longest list %u, lists per query %u, kprime %u, kseed %u, pre_tiles %u\n",
+                (double)tot / std::max<uint32_t>(q, 1), mx, n_lists, kprime, sp.kseed, seeded ? pre_tiles : 0);
+    }
 
     PostParams pp{};
     pp.base_raw = ix->d_raw;
@@ -504,7 +542,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     pp.out_ids = d_out_ids;
     pp.out_dists = d_out_dists;
     pp.out_counts = d_out_counts;
-    pp.q = q; pp.n = n; pp.dim = ix->dim; pp.k = k; pp.kprime = kprime; pp.cap = cap; pp.n_splits = plan.n_splits;
+    pp.q = q; pp.n = n; pp.dim = ix->dim; pp.k = k; pp.kprime = kprime; pp.cap = cap; pp.n_splits = n_lists;
     pp.metric = ix->metric; pp.arith = ix->arith; pp.precision = precision;
     pp.max_norm = ix->max_norm;
     if (sq8) {

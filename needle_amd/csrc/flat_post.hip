@@ -21,14 +21,23 @@ __global__ __launch_bounds__(64) void merge_select_kernel(PostParams p) {
     extern __shared__ __attribute__((aligned(16))) uint64_t mkeys[];
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
     uint32_t total = 0;
-    for (uint32_t s = 0; s < p.n_splits; ++s) {
-        const uint32_t c = min(p.list_counts[(uint64_t)q * p.n_splits + s], p.kprime);  // a slice keeps <= kprime
-        const uint2* l = p.lists + ((uint64_t)q * p.n_splits + s) * p.cap;
-        for (uint32_t i = lane; i < c; i += 64) {
-            const uint2 v = l[i];
-            mkeys[total + i] = cand_key(v.x, v.y);
+    // lane l copies list l0 + l: the lists are short, so the 64 copies run side by side
+    for (uint32_t l0 = 0; l0 < p.n_splits; l0 += 64) {
+        const uint32_t li = l0 + lane;
+        const uint32_t c = li < p.n_splits ? min(p.list_counts[(uint64_t)q * p.n_splits + li], p.kprime) : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
+            if (lane >= (uint32_t)off) incl += t;
         }
-        total += c;
+        const uint32_t dst = total + incl - c;
+        const uint2* l = p.lists + ((uint64_t)q * p.n_splits + li) * p.cap;
+        for (uint32_t i = 0; i < c; ++i) {
+            const uint2 v = l[i];
+            mkeys[dst + i] = cand_key(v.x, v.y);
+        }
+        total += (uint32_t)__shfl((int)incl, 63);
     }
     __syncthreads();
     uint64_t prefix = 0;
@@ -147,27 +156,151 @@ __device__ inline bool bound_check_sq8(float tau, float dk, double qconst, doubl
 // Reference-order distance of every candidate, rank by (distance, id), emit the
 // k best, run the bound check on the k-th.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rescore_finalize_kernel(PostParams p) {
+// The candidate rows are staged through LDS a block of dimensions at a time (coalesced reads of
+// whole row segments), then thread j walks candidate j's staged segment in dimension order, so
+// the arithmetic is the scalar sequence of nh_exact.h continued across the blocks.
+struct RefAcc { float a, b, c; };  // running sums: a = dot | squared distance, b = |q|^2, c = |row|^2
+
+enum RefKind { RK_RS_COS, RK_RS_DOT, RK_RS_L2, RK_C4_COS, RK_C4_DOT, RK_C4_L2 };
+
+__device__ inline int ref_kind(int metric, int arith) {
+    if (arith == NEEDLE_ARITH_ACCEL_CHUNK4)
+        return metric == NEEDLE_METRIC_COSINE ? RK_C4_COS : (metric == NEEDLE_METRIC_EUCLIDEAN ? RK_C4_L2 : RK_C4_DOT);
+    return metric == NEEDLE_METRIC_COSINE ? RK_RS_COS : (metric == NEEDLE_METRIC_EUCLIDEAN ? RK_RS_L2 : RK_RS_DOT);
+}
+
+// dims [i0, i1) of the vectors, staged at qs[0 .. i1-i0) and bs[0 .. i1-i0); i0 is a multiple of 4
+template <int KIND>
+__device__ inline void ref_accumulate(RefAcc& s, const float* qs, const float* bs, uint32_t i0, uint32_t i1, uint32_t dim) {
+    if (KIND == RK_RS_COS) {  // distance.rs:153-164
+        for (uint32_t i = 0; i < i1 - i0; ++i) {
+            const float x = qs[i], y = bs[i];
+            const float pxy = x * y; s.a = s.a + pxy;
+            const float pxx = x * x; s.b = s.b + pxx;
+            const float pyy = y * y; s.c = s.c + pyy;
+        }
+    } else if (KIND == RK_RS_DOT) {  // distance.rs:193-196, 264-266
+        for (uint32_t i = 0; i < i1 - i0; ++i) { const float pxy = qs[i] * bs[i]; s.a = s.a + pxy; }
+    } else if (KIND == RK_RS_L2) {  // distance.rs:249-257
+        for (uint32_t i = 0; i < i1 - i0; ++i) { const float d = qs[i] - bs[i]; const float pd = d * d; s.a = s.a + pd; }
+    } else {  // gpu/common.rs:515-581: groups of four, then the remainder one by one
+        const uint32_t grouped = (dim / 4) * 4;
+        uint32_t i = i0;
+        for (; i + 4 <= min(i1, grouped); i += 4) {
+            const float* x = qs + (i - i0);
+            const float* y = bs + (i - i0);
+            if (KIND == RK_C4_L2) {
+                const float d0 = x[0] - y[0], d1 = x[1] - y[1], d2 = x[2] - y[2], d3 = x[3] - y[3];
+                const float s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2, s3 = d3 * d3;
+                const float g = ((s0 + s1) + s2) + s3;
+                s.a = s.a + g;
+            } else {
+                const float p0 = x[0] * y[0], p1 = x[1] * y[1], p2 = x[2] * y[2], p3 = x[3] * y[3];
+                const float g = ((p0 + p1) + p2) + p3;
+                s.a = s.a + g;
+                if (KIND == RK_C4_COS) {
+                    const float a0 = x[0] * x[0], a1 = x[1] * x[1], a2 = x[2] * x[2], a3 = x[3] * x[3];
+                    const float ga = ((a0 + a1) + a2) + a3;
+                    s.b = s.b + ga;
+                    const float b0 = y[0] * y[0], b1 = y[1] * y[1], b2 = y[2] * y[2], b3 = y[3] * y[3];
+                    const float gb = ((b0 + b1) + b2) + b3;
+                    s.c = s.c + gb;
+                }
+            }
+        }
+        for (; i < i1; ++i) {
+            const float x = qs[i - i0], y = bs[i - i0];
+            if (KIND == RK_C4_L2) {
+                const float d = x - y; const float pd = d * d; s.a = s.a + pd;
+            } else {
+                const float pxy = x * y; s.a = s.a + pxy;
+                if (KIND == RK_C4_COS) {
+                    const float pxx = x * x; s.b = s.b + pxx;
+                    const float pyy = y * y; s.c = s.c + pyy;
+                }
+            }
+        }
+    }
+}
+
+__device__ inline float ref_finish(int kind, const RefAcc& s) {
+    switch (kind) {
+    case RK_RS_COS:
+    case RK_C4_COS: {
+        const float na = sqrtf(s.b);
+        if (kind == RK_C4_COS && na == 0.0f) return 1.0f;  // gpu/mod.rs:717-762: query norm first
+        const float nb = sqrtf(s.c);
+        if (na == 0.0f || nb == 0.0f) return 1.0f;
+        const float den = na * nb;
+        return 1.0f - (s.a / den);
+    }
+    case RK_RS_L2:
+    case RK_C4_L2: return sqrtf(s.a);
+    default: return s.a;  // caller applies 1 - dot or -dot
+    }
+}
+
+constexpr int RS_THREADS = 256;
+
+__global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams p, uint32_t dc) {
+    extern __shared__ __attribute__((aligned(16))) float stage[];  // [dc] query block, then [nc][dc + 1] row blocks
     __shared__ uint64_t skey[KPRIME_MAX];
-    __shared__ float sdist[KPRIME_MAX];
+    __shared__ uint32_t spos[KPRIME_MAX];
     const uint32_t q = blockIdx.x, j = threadIdx.x;
     const uint32_t nc = min(p.cand_n[q], p.kprime);
     const uint32_t k_eff = min(p.k, nc);
     uint64_t key = ~0ull;
     float d = 0.0f;
-    uint32_t id = 0;
+    uint32_t id = 0, pos = 0;
     if (j < nc) {
-        const uint32_t pos = p.cand_ids[(uint64_t)q * p.kprime + j];
+        pos = p.cand_ids[(uint64_t)q * p.kprime + j];
         id = p.pos2id ? p.pos2id[pos] : pos;
-        if (p.sq_codes)
+    }
+    if (j < KPRIME_MAX) spos[j] = pos;
+    if (p.sq_codes) {
+        if (j < nc)
             d = canon_distance(exact_sq8(p.query_raw + (uint64_t)q * p.dim, p.sq_codes + (uint64_t)pos * p.sq_stride,
                                          p.sq_min, p.sq_scale, p.dim));
-        else
-            d = canon_distance(exact_distance(p.metric, p.arith, p.query_raw + (uint64_t)q * p.dim,
-                                              p.base_raw + (uint64_t)pos * p.dim, p.dim));
-        key = hit_key(d, id);
+    } else {
+        const int kind = ref_kind(p.metric, p.arith);
+        RefAcc acc;
+        const float zero = p.arith == NEEDLE_ARITH_ACCEL_CHUNK4 ? 0.0f : -0.0f;  // Rust's f32 Sum folds from -0.0
+        acc.a = zero; acc.b = zero; acc.c = zero;
+        float* qs = stage;
+        float* rows = stage + dc;
+        const uint32_t ld = dc + 1;  // odd stride: thread j's walk over row j is bank-conflict free
+        const uint32_t wave = j >> 6, lane = j & 63;
+        const float* qsrc = p.query_raw + (uint64_t)q * p.dim;
+        for (uint32_t c0 = 0; c0 < p.dim; c0 += dc) {
+            const uint32_t len = min(dc, p.dim - c0);
+            __syncthreads();  // the previous block has been consumed (and spos is visible)
+            for (uint32_t i = j; i < len; i += RS_THREADS) qs[i] = qsrc[c0 + i];
+            for (uint32_t r = wave; r < nc; r += RS_THREADS / 64) {
+                const float* src = p.base_raw + (uint64_t)spos[r] * p.dim + c0;
+                for (uint32_t i = lane; i < len; i += 64) rows[r * ld + i] = src[i];
+            }
+            __syncthreads();
+            if (j < nc) {
+                const float* bs = rows + j * ld;
+                switch (kind) {
+                case RK_RS_COS: ref_accumulate<RK_RS_COS>(acc, qs, bs, c0, c0 + len, p.dim); break;
+                case RK_RS_DOT: ref_accumulate<RK_RS_DOT>(acc, qs, bs, c0, c0 + len, p.dim); break;
+                case RK_RS_L2: ref_accumulate<RK_RS_L2>(acc, qs, bs, c0, c0 + len, p.dim); break;
+                case RK_C4_COS: ref_accumulate<RK_C4_COS>(acc, qs, bs, c0, c0 + len, p.dim); break;
+                case RK_C4_DOT: ref_accumulate<RK_C4_DOT>(acc, qs, bs, c0, c0 + len, p.dim); break;
+                default: ref_accumulate<RK_C4_L2>(acc, qs, bs, c0, c0 + len, p.dim); break;
+                }
+            }
+        }
+        if (j < nc) {
+            float v = ref_finish(kind, acc);
+            if (kind == RK_RS_DOT || kind == RK_C4_DOT)
+                v = p.metric == NEEDLE_METRIC_COSINE_NORMALIZED ? 1.0f - v : -v;
+            d = canon_distance(v);
+        }
     }
-    if (j < KPRIME_MAX) { skey[j] = key; sdist[j] = d; }
+    if (j < nc) key = hit_key(d, id);
+    if (j < KPRIME_MAX) skey[j] = key;
     __syncthreads();
     if (j < nc) {
         uint32_t rank = 0;
@@ -192,8 +325,13 @@ __global__ __launch_bounds__(256) void rescore_finalize_kernel(PostParams p) {
 
 hipError_t launch_rescore_finalize(const PostParams& p, hipStream_t stream) {
     if (p.q == 0) return hipSuccess;
-    const uint32_t threads = ((p.kprime + 63) / 64) * 64;
-    hipLaunchKernelGGL(rescore_finalize_kernel, dim3(p.q), dim3(threads), 0, stream, p);
+    // block of dimensions staged at a time: a multiple of 4 (groups of four never straddle blocks), the
+    // row blocks of all kprime candidates within 48 KB
+    uint32_t dc = (48u * 1024u / 4u) / p.kprime;
+    dc = dc > 129 ? 128 : ((dc - 1) / 4) * 4;
+    if (dc < 4) dc = 4;
+    const size_t lds = ((size_t)dc + (size_t)p.kprime * (dc + 1)) * sizeof(float);
+    hipLaunchKernelGGL(rescore_finalize_kernel, dim3(p.q), dim3(RS_THREADS), lds, stream, p, dc);
     return hipGetLastError();
 }
 

@@ -21,34 +21,10 @@
 // reference's scalar order afterwards (flat_post.hip).
 #include "nh_common.h"
 #include "nh_kernels.h"
+#include "nh_scan.h"
 #include "nh_select.h"
 
 namespace nh {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-enum ScanMode { MODE_FLAT = 0, MODE_PRE = 1, MODE_IVF = 2 };
-
-// accumulator register r of lane half h holds result row (r&3) + 8*(r>>2) + 4*h
-__device__ inline uint32_t row_of_reg(int r, uint32_t h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-// May row `row` be returned?  FLAT: row < n and mask bits of the row; IVF: the
-// position maps to a real row whose mask bits (by original id) are set.
-template <int MODE>
-__device__ inline bool row_live(const ScanParams& p, uint32_t row) {
-    if (MODE == MODE_IVF) {
-        const uint32_t id = p.pos2id[row];
-        if (id == 0xffffffffu) return false;
-        if (p.valid && !bit_set(p.valid, id)) return false;
-        if (p.filter && !bit_set(p.filter, id)) return false;
-        return true;
-    }
-    if (row >= p.n) return false;
-    if (p.valid && !bit_set(p.valid, row)) return false;
-    if (p.filter && !bit_set(p.filter, row)) return false;
-    return true;
-}
 
 // Append the passing results of one 32x32 tile (16 accumulator registers per
 // lane) and compact the lists that filled up.  `acc` rows are rows
@@ -146,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
 
     float tau = -INFINITY;
     if (MODE != MODE_PRE && p.tau0 && q_live) tau = p.tau0[my_query];
-    if (!q_live || (p.debug & 1u)) tau = INFINITY;
+    if (!q_live || (p.debug & 1u) || (MODE != MODE_IVF && my_query >= p.n_queries)) tau = INFINITY;
     uint32_t cnt = 0;
     float gmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // MODE_PRE: this lane's group maxima
 
@@ -297,7 +273,7 @@ hipError_t launch_flat_scan(int precision, const ScanParams& p, hipStream_t stre
         if (p.base_is_u8) hipLaunchKernelGGL((flat_scan_f32_kernel<MODE_FLAT, true>), dim3(grid), dim3(256), 0, stream, p);
         else hipLaunchKernelGGL(flat_scan_f32_kernel<MODE_FLAT>, dim3(grid), dim3(256), 0, stream, p);
     } else {
-        return hipErrorInvalidValue;
+        return launch_flat_scan_bf16(p, false, stream);
     }
     return hipGetLastError();
 }
@@ -309,10 +285,11 @@ hipError_t launch_flat_prepass(int precision, const ScanParams& p, float* d_tau0
         if (p.base_is_u8) hipLaunchKernelGGL((flat_scan_f32_kernel<MODE_PRE, true>), dim3(grid), dim3(256), 0, stream, p);
         else hipLaunchKernelGGL(flat_scan_f32_kernel<MODE_PRE>, dim3(grid), dim3(256), 0, stream, p);
     } else {
-        return hipErrorInvalidValue;
+        const hipError_t e = launch_flat_scan_bf16(p, true, stream);
+        if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(tau0_kernel, dim3(p.q_tiles * TILE_QUERIES), dim3(64), 0, stream, p.pre_max, 8 * p.n_splits,
-                       p.kprime, d_tau0);
+    hipLaunchKernelGGL(tau0_kernel, dim3(p.q_tiles * flat_scan_queries_per_block(precision, p.dpad)), dim3(64), 0, stream,
+                       p.pre_max, 8 * p.n_splits, p.kseed, d_tau0);
     return hipGetLastError();
 }
 
@@ -328,8 +305,12 @@ int flat_scan_blocks_per_cu(int precision) {
     hipError_t e = hipErrorInvalidValue;
     if (precision == NEEDLE_PRECISION_FP32)
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, flat_scan_f32_kernel<MODE_FLAT>, 256, 0);
-    if (e != hipSuccess || nb < 1) nb = 1;
+    if (e != hipSuccess || nb < 1) nb = 1;  // bf16: one workgroup per CU by design (one wave per SIMD)
     return nb;
+}
+
+uint32_t flat_scan_queries_per_block(int precision, uint32_t dpad) {
+    return precision == NEEDLE_PRECISION_FP32 ? (uint32_t)TILE_QUERIES : flat_scan_bf16_queries_per_block(dpad);
 }
 
 uint32_t flat_scan_kstep(int precision) { return precision == NEEDLE_PRECISION_FP32 ? F32_BK : 64; }

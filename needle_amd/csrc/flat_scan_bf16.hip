@@ -1,0 +1,335 @@
+// bf16 first pass of the exact flat search: v_mfma_f32_32x32x16_bf16, f32 accumulate.
+//
+// Structure (one workgroup = 4 waves, ONE wave per SIMD, the whole 512-register file per wave):
+//   * the queries are stationary IN REGISTERS: wave w holds the B fragments of its own
+//     32*NT queries for the full dimension (NT * KS fragments of 8 bf16), loaded once;
+//   * the rows stream through a ring of LDS slots, one slot = 64 rows x 128 dims (16 KB), filled
+//     by direct-to-LDS loads three stages ahead of the MFMAs.  A wave-instruction of such a load
+//     writes 1 KB linearly (4 rows x 256 B), so the bank-conflict swizzle (16-byte chunk c of row r
+//     lives at chunk c ^ (r & 15)) is applied to the per-lane SOURCE address;
+//   * every wave multiplies ALL 64 staged rows with ITS queries: 2 row tiles x NT query
+//     tiles of 32x32, so one 16-byte LDS fragment feeds NT MFMAs and the rows are fetched
+//     from L2/HBM once per 128*NT queries.  A 128-row tile is walked as two half tiles, which
+//     keeps the accumulators at 32*NT registers beside the 4*NT*KS registers of query fragments.
+// One barrier per stage; the loads in flight are retired by counted vmcnt waits, never vmcnt(0).
+//
+// Selection: as in the fp32 kernel each lane compares its 16 results per tile with its
+// query's threshold; here every LANE owns its candidate list (query, slice, lane half), so a
+// push is a predicated store and a counter increment with no cross-lane step.
+#include "nh_common.h"
+#include "nh_kernels.h"
+#include "nh_scan.h"
+#include "nh_select.h"
+
+#include <type_traits>
+#include <utility>
+
+namespace nh {
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>)
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+constexpr int BF_ROWS = 64;                               // rows per stage: half a 128-row tile
+constexpr int BF_BK = 128;                                // dims per stage
+constexpr int BF_STAGE_BYTES = BF_ROWS * BF_BK * 2;       // 16 KB
+constexpr int BF_NBUF = 4;                                // ring slots
+constexpr int BF_PD = 3;                                  // stages in flight ahead of the one being multiplied
+constexpr int BF_CSLOT = 1024;                            // per slot: the half tile's accumulator seeds, once per wave
+constexpr int BF_LDS_BYTES = BF_NBUF * (BF_STAGE_BYTES + BF_CSLOT);
+
+// byte offset of 16-byte chunk c (0..15) of row r (0..63) inside a stage: rows are 256 B = one sweep of
+// the LDS banks, so the 16 rows one ds_read_b128 phase touches are spread over the 16 chunk positions
+__device__ inline uint32_t bf_lds_off(uint32_t r, uint32_t c) { return r * 256u + ((c ^ (r & 15u)) << 4); }
+
+template <int MODE>
+__device__ inline void push_lane(const f32x16& acc, uint32_t row_base, uint32_t h, uint32_t lane, const ScanParams& p,
+                                 uint32_t list_idx, float& tau, uint32_t& cnt) {
+    const float g0 = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+    const float g1 = fmaxf(fmaxf(acc[4], acc[5]), fmaxf(acc[6], acc[7]));
+    const float g2 = fmaxf(fmaxf(acc[8], acc[9]), fmaxf(acc[10], acc[11]));
+    const float g3 = fmaxf(fmaxf(acc[12], acc[13]), fmaxf(acc[14], acc[15]));
+    const float m = fmaxf(fmaxf(g0, g1), fmaxf(g2, g3));
+    if (__builtin_amdgcn_ballot_w64(m > tau) == 0) return;  // wave-uniform
+    uint2* mylist = p.lists + (uint64_t)list_idx * p.cap;
+    const float gm[4] = {g0, g1, g2, g3};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (gm[g] > tau) {  // rows 8g + 4h .. + 3 of the tile
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float key = acc[4 * g + j];
+                if (key > tau) {
+                    const uint32_t row = row_base + row_of_reg(4 * g + j, h);
+                    if (row_live<MODE>(p, row)) {
+                        mylist[cnt] = make_uint2(__float_as_uint(key), row);
+                        cnt += 1;
+                    }
+                }
+            }
+        }
+    }
+    uint64_t need = __builtin_amdgcn_ballot_w64(cnt > p.cap - 16);
+    while (need) {
+        const uint32_t b = (uint32_t)__builtin_ctzll(need);
+        need &= need - 1;
+        const uint32_t n_e = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)b);
+        const uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)list_idx, (int)b);
+        const float t = wave_compact_list(p.lists + (uint64_t)li * p.cap, n_e, p.kprime, lane);
+        if (lane == b) { tau = t; cnt = p.kprime; }
+    }
+}
+
+// direct-to-LDS loads a wave issues for stage u of a tile (u = half * STAGES + s, taken modulo the tile)
+template <int STAGES, bool CINIT>
+constexpr int bf_stage_loads(int u) { return 4 + ((CINIT && (u % STAGES) == 0) ? 1 : 0); }
+// loads issued behind stage u that may still be in flight when stage u is awaited
+template <int STAGES, bool CINIT>
+constexpr int bf_inflight_behind(int u) {
+    int n = 0;
+    for (int j = 1; j < BF_PD; ++j) n += bf_stage_loads<STAGES, CINIT>(u + j);
+    return n;
+}
+
+// NT query tiles per wave, KS k-steps of 16 dims (dpad = 16 * KS).  Queries per workgroup = 128 * NT.
+template <int MODE, int NT, int KS, bool CINIT>
+__global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[BF_LDS_BYTES];
+    constexpr int STAGES = KS / 8;       // stages per half tile
+    constexpr int UT = 2 * STAGES;       // stages per tile
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t l31 = lane & 31, h = lane >> 5;
+    constexpr uint32_t QB = 128 * NT;
+
+    uint32_t split, q_tile;
+    if (p.xcd_map) {
+        const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        split = xcd + 8 * (j / p.q_tiles);
+        q_tile = j % p.q_tiles;
+    } else {
+        split = blockIdx.x / p.q_tiles;
+        q_tile = blockIdx.x % p.q_tiles;
+    }
+    const uint32_t q0 = q_tile * QB + wave * (32 * NT);  // first query of this wave
+    const uint32_t t0 = split * p.tiles_per_split;
+    uint32_t t1 = min(t0 + p.tiles_per_split, p.n_tiles);
+    if (MODE == MODE_PRE) t1 = min(t1, t0 + p.pre_tiles);
+
+    float tau[NT];
+    uint32_t cnt[NT], list_idx[NT];
+    float gmax[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const uint32_t my_query = q0 + nt * 32 + l31;
+        list_idx[nt] = (my_query * p.n_splits + split) * 2 + h;
+        tau[nt] = -INFINITY;
+        if (MODE != MODE_PRE && p.tau0) tau[nt] = p.tau0[my_query];
+        if ((p.debug & 1u) || my_query >= p.n_queries) tau[nt] = INFINITY;
+        cnt[nt] = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gmax[nt][g] = -INFINITY;
+    }
+
+    if (t1 > t0) {  // block-uniform
+        // stationary query fragments: lane (l31, h) holds dims 16*ks + 8*h .. +7 of query q0 + 32*nt + l31
+        bf16x8 bq[NT][KS];
+        const uint16_t* __restrict__ gB = (const uint16_t*)p.query_op;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const uint16_t* qrow = gB + (uint64_t)(q0 + nt * 32 + l31) * p.dpad + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bq[nt][ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(qrow + ks * 16));
+                // keep the fragment in the accumulation half of the register file: the MFMA reads its B
+                // operand from there directly, and the other half stays free for the row fragments
+                asm volatile("" : "+a"(bq[nt][ks]));
+            }
+        }
+
+        const unsigned char* __restrict__ gA = (const unsigned char*)p.base_op;
+        const uint32_t row_bytes = p.dpad * 2;
+        // piece i (0..3) of this wave = rows (wave*4+i)*4 .. +3 of the stage; lane -> (row, physical chunk)
+        uint32_t src_off[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t r = (wave * 4 + i) * 4 + (lane >> 4), cphys = lane & 15;
+            src_off[i] = r * row_bytes + ((cphys ^ (r & 15u)) << 4);
+        }
+        // fill slot `slot` with stage u (0 .. UT-1) of tile `tile` (tile clamped by the caller)
+        auto issue_stage = [&](uint32_t tile, int u, uint32_t slot) {
+            const uint32_t half = (uint32_t)(u / STAGES), s2 = (uint32_t)(u % STAGES);
+            const unsigned char* src = gA + (uint64_t)(tile * TILE_ROWS + half * BF_ROWS) * row_bytes + s2 * 256u;
+            unsigned char* dst = smem + slot * BF_STAGE_BYTES + wave * 4096u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((glb_void*)(src + src_off[i]), (lds_void*)(dst + i * 1024), 16, 0, 0);
+            if (CINIT && s2 == 0)
+                __builtin_amdgcn_global_load_lds((glb_void*)(p.cinit + (uint64_t)tile * TILE_ROWS + half * BF_ROWS + lane),
+                                                 (lds_void*)(smem + BF_NBUF * BF_STAGE_BYTES + slot * BF_CSLOT + wave * 256u), 4,
+                                                 0, 0);
+        };
+
+        // prologue: the first PD stages of the block's run (clamped to its last tile: surplus fills are harmless)
+#pragma unroll
+        for (int j = 0; j < BF_PD; ++j) issue_stage(min(t0 + (uint32_t)(j / UT), t1 - 1), j % UT, (uint32_t)j);
+
+        f32x16 acc[2][NT];
+        uint32_t slot = 0;  // slot of the stage being multiplied
+        for (uint32_t tile = t0; tile < t1; ++tile) {
+            static_for<2>([&](auto half_c) {
+                constexpr int half = decltype(half_c)::value;
+                static_for<STAGES>([&](auto s_c) {
+                    constexpr int s = decltype(s_c)::value;
+                    constexpr int u = half * STAGES + s;
+                    // this wave's pieces of the stage have landed; after the barrier everybody's have, and
+                    // everybody is done reading the previous stage's slot
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_inflight_behind<STAGES, CINIT>(u)) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                    issue_stage(min(tile + (uint32_t)((u + BF_PD) / UT), t1 - 1), (u + BF_PD) % UT, (slot + BF_PD) % BF_NBUF);
+                    const unsigned char* As = smem + slot * BF_STAGE_BYTES;
+                    if (s == 0) {
+                        if (CINIT) {
+                            const float* cs = (const float*)(smem + BF_NBUF * BF_STAGE_BYTES + slot * BF_CSLOT + wave * 256u);
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const f32x4 v = *(const f32x4*)(cs + mt * 32 + 8 * j + 4 * h);
+#pragma unroll
+                                    for (int nt = 0; nt < NT; ++nt) {
+                                        acc[mt][nt][4 * j + 0] = v[0];
+                                        acc[mt][nt][4 * j + 1] = v[1];
+                                        acc[mt][nt][4 * j + 2] = v[2];
+                                        acc[mt][nt][4 * j + 3] = v[3];
+                                    }
+                                }
+                        } else {
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+                        }
+                    }
+                    // fragments of k-step kk+1 are read while the MFMAs of k-step kk run
+                    bf16x8 a[2][2];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        a[0][mt] = __builtin_bit_cast(bf16x8, *(const uint4*)(As + bf_lds_off(mt * 32 + l31, h)));
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        if (kk + 1 < 8) {
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt)
+                                a[(kk + 1) & 1][mt] = __builtin_bit_cast(
+                                    bf16x8, *(const uint4*)(As + bf_lds_off(mt * 32 + l31, (kk + 1) * 2 + h)));
+                        }
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk & 1][mt], bq[nt][s * 8 + kk],
+                                                                                     acc[mt][nt], 0, 0, 0);
+                        if (kk + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 LDS reads
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);             // the k-step's MFMAs
+                    }
+                    slot = (slot + 1) % BF_NBUF;
+                });
+                // selection behind the half tile
+                const uint32_t row0 = tile * TILE_ROWS + half * BF_ROWS;
+                if (MODE == MODE_PRE) {
+                    const bool plain = !p.valid && !p.filter && (tile + 1) * TILE_ROWS <= p.n;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                bool ok = true;
+                                if (!plain) ok = row_live<MODE_FLAT>(p, row0 + mt * 32 + row_of_reg(r, h));
+                                if (ok) gmax[nt][half * 2 + mt] = fmaxf(gmax[nt][half * 2 + mt], acc[mt][nt][r]);
+                            }
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            push_lane<MODE>(acc[mt][nt], row0 + mt * 32, h, lane, p, list_idx[nt], tau[nt], cnt[nt]);
+                }
+            });
+        }
+        // the surplus fills issued behind the last stage must land before the LDS is given back
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    if (MODE == MODE_PRE) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float* dst = p.pre_max + (uint64_t)(q0 + nt * 32 + l31) * (8 * p.n_splits) + (split * 2 + h) * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dst[g] = gmax[nt][g];
+        }
+        return;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        uint64_t need = __builtin_amdgcn_ballot_w64(cnt[nt] > p.kprime);
+        while (need) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(need);
+            need &= need - 1;
+            const uint32_t n_e = (uint32_t)__builtin_amdgcn_readlane((int)cnt[nt], (int)b);
+            const uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)list_idx[nt], (int)b);
+            wave_compact_list(p.lists + (uint64_t)li * p.cap, n_e, p.kprime, lane);
+            if (lane == b) cnt[nt] = p.kprime;
+        }
+        p.list_counts[list_idx[nt]] = cnt[nt];
+    }
+}
+
+// dpad (dims padded to a supported k-step count) and queries per workgroup for a dimension; 0 = unsupported
+uint32_t flat_scan_bf16_dpad(uint32_t dim) {
+    const uint32_t ks = (dim + 15) / 16;
+    if (ks <= 8) return 128;
+    if (ks <= 16) return 256;
+    if (ks <= 24) return 384;
+    if (ks <= 32) return 512;
+    if (ks <= 48) return 768;
+    return 0;
+}
+uint32_t flat_scan_bf16_queries_per_block(uint32_t dpad) { return dpad <= 384 ? 256 : 128; }
+
+template <int MODE, bool CINIT>
+static hipError_t launch_bf16_mode(const ScanParams& p, hipStream_t stream) {
+    const dim3 grid(p.n_splits * p.q_tiles), block(256);
+    switch (p.dpad) {
+    case 128: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE, 2, 8, CINIT>), grid, block, 0, stream, p); break;
+    case 256: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE, 2, 16, CINIT>), grid, block, 0, stream, p); break;
+    case 384: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE, 2, 24, CINIT>), grid, block, 0, stream, p); break;
+    case 512: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE, 1, 32, CINIT>), grid, block, 0, stream, p); break;
+    case 768: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE, 1, 48, CINIT>), grid, block, 0, stream, p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_flat_scan_bf16(const ScanParams& p, bool prepass, hipStream_t stream) {
+    if (p.n_splits * p.q_tiles == 0) return hipSuccess;
+    if (p.cinit)
+        return prepass ? launch_bf16_mode<MODE_PRE, true>(p, stream) : launch_bf16_mode<MODE_FLAT, true>(p, stream);
+    return prepass ? launch_bf16_mode<MODE_PRE, false>(p, stream) : launch_bf16_mode<MODE_FLAT, false>(p, stream);
+}
+
+}  // namespace nh

@@ -75,7 +75,8 @@ struct ScanParams {
     uint32_t n_tiles;         // ceil(n / TILE_ROWS)
     uint32_t tiles_per_split;
     uint32_t n_splits;
-    uint32_t q_tiles;         // q_pad / TILE_QUERIES
+    uint32_t q_tiles;         // q_pad / queries per workgroup
+    uint32_t n_queries;       // real queries; the padding slots up to q_pad never list a candidate
     uint32_t dpad;            // padded dimension, multiple of the k-step
     uint32_t kprime;
     uint32_t cap;
@@ -87,6 +88,7 @@ struct ScanParams {
     float* pre_max;           // [q_pad][8 * n_splits] (pre-pass output)
     const float* tau0;        // [q_pad] starting threshold of the main pass, or null
     uint32_t pre_tiles;
+    uint32_t kseed;           // rank of the seeded threshold among the sampled group maxima (k <= kseed <= kprime)
     // inverted-list scan: one workgroup per work item = (one list's row tiles) x (<= 128 of the
     // queries probing that list); rows are positions in the list-ordered copy of the base
     const IvfItem* items;     // [grid]

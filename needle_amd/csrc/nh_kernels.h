@@ -12,6 +12,16 @@ hipError_t launch_flat_prepass(int precision, const ScanParams& p, float* d_tau0
 hipError_t launch_ivf_scan(int precision, const ScanParams& p, uint32_t n_items, hipStream_t stream);
 int flat_scan_blocks_per_cu(int precision);
 uint32_t flat_scan_kstep(int precision);
+// queries one workgroup of the flat scan serves (q_pad is a multiple of it)
+uint32_t flat_scan_queries_per_block(int precision, uint32_t dpad);
+
+// ---- flat_scan_bf16.hip ----------------------------------------------------
+// Padded operand dimension of the bf16 scan for `dim`, 0 when the dimension is beyond what the
+// query-stationary kernel holds in registers (then the fp32 scan serves the search).
+uint32_t flat_scan_bf16_dpad(uint32_t dim);
+uint32_t flat_scan_bf16_queries_per_block(uint32_t dpad);
+// Candidate lists are per (query, slice, lane half): 2 * n_splits lists per query.
+hipError_t launch_flat_scan_bf16(const ScanParams& p, bool prepass, hipStream_t stream);
 
 // ---- prep.hip --------------------------------------------------------------
 // Per row: |b|, |b|^2 (wave-parallel sums; used by the first pass and its error

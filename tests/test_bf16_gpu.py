@@ -1,0 +1,139 @@
+"""The bf16 first pass (precision="bf16") returns the SAME hits as the fp32 one: the reduced
+precision only widens the candidate filter; reported ids and distances stay bit-equal to the
+oracle's reference-order arithmetic, with the bound check (and the exact scan behind it) covering
+every query the coarser scores cannot decide."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+F = np.float32
+U64MAX = np.iinfo(np.uint64).max
+METRICS4 = ["Cosine", "CosineNormalized", "Euclidean", "DotProduct"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import needle_amd as na
+
+    c = na.Context(0)
+    yield c
+    c.close()
+
+
+def _data(seed, n, d, q, unit=False):
+    rng = np.random.default_rng(seed)
+    b = rng.standard_normal((n, d)).astype(F)
+    qq = rng.standard_normal((q, d)).astype(F)
+    if unit:
+        b /= np.linalg.norm(b, axis=1, keepdims=True)
+        qq /= np.linalg.norm(qq, axis=1, keepdims=True)
+    return b.astype(F), qq.astype(F)
+
+
+def _check(oracle, got, base, queries, k, metric, valid=None, filt=None):
+    ids, dists, counts = got
+    oi, od, oc = oracle.flat_batch_search(queries, base, k, int(metric), valid=valid, filt=filt)
+    assert np.array_equal(counts, oc), (counts[:8], oc[:8])
+    for i in range(queries.shape[0]):
+        c = int(oc[i])
+        assert np.array_equal(ids[i, :c], oi[i, :c]), (i, ids[i, :c], oi[i, :c])
+        assert np.array_equal(dists[i, :c].view(np.uint32), od[i, :c].view(np.uint32)), (i, dists[i, :c], od[i, :c])
+        assert np.all(ids[i, c:] == U64MAX) and np.all(np.isinf(dists[i, c:]))
+
+
+# every register-resident query layout: dpad 128, 256, 384 (two query tiles per wave), 512, 768 (one)
+@pytest.mark.parametrize("metric", METRICS4)
+@pytest.mark.parametrize("shape", [(3000, 100, 130, 10), (517, 33, 3, 1), (9000, 200, 300, 10), (6000, 384, 270, 10),
+                                   (4000, 500, 140, 5), (3000, 768, 40, 10)])
+def test_bf16_shapes_all_metrics(ctx, oracle, metric, shape):
+    import needle_amd as na
+
+    n, d, q, k = shape
+    base, queries = _data(31 + d, n, d, q, unit=(metric == "CosineNormalized"))
+    m = na.DistanceFunction[metric]
+    ix = na.FlatIndex(ctx, base, m)
+    _check(oracle, ix.search(queries, k, precision="bf16"), base, queries, k, m)
+    ix.close()
+
+
+@pytest.mark.parametrize("metric", ["Cosine", "Euclidean"])
+def test_bf16_long_slices_seeded_threshold_and_masks(ctx, oracle, metric):
+    import needle_amd as na
+
+    n, d, q, k = 200_000, 48, 300, 10
+    base, queries = _data(41, n, d, q)
+    m = na.DistanceFunction[metric]
+    rng = np.random.default_rng(3)
+    valid = rng.random(n) > 0.2
+    filt = rng.random(n) < 0.1
+    ix = na.FlatIndex(ctx, base, m)
+    _check(oracle, ix.search(queries, k, precision="bf16"), base, queries, k, m)
+    ix.set_valid_mask(valid)
+    _check(oracle, ix.search(queries, k, precision="bf16", filter_mask=filt), base, queries, k, m, valid=valid, filt=filt)
+    ix.close()
+
+
+def test_bf16_readme_shape_scaled(ctx, oracle):
+    import needle_amd as na
+
+    base, queries = _data(2, 60000, 384, 600, unit=True)
+    ix = na.FlatIndex(ctx, base, na.DistanceFunction.Cosine)
+    ctx.reset_metrics()
+    _check(oracle, ix.search(queries, 10, precision="bf16"), base, queries, 10, na.DistanceFunction.Cosine)
+    # well separated random embeddings: the bf16 filter decides nearly every query on its own
+    assert ctx.metrics()["fallback_queries"] <= 6
+    ix.close()
+
+
+def test_bf16_sorted_base_and_large_k(ctx, oracle):
+    import needle_amd as na
+
+    base, queries = _data(22, 60_000, 24, 8)
+    order = np.argsort(-((base - queries[0]) ** 2).sum(axis=1))
+    base = np.ascontiguousarray(base[order])  # farthest first: every tile beats the running threshold
+    m = na.DistanceFunction.Euclidean
+    ix = na.FlatIndex(ctx, base, m)
+    _check(oracle, ix.search(queries, 10, precision="bf16"), base, queries, 10, m)
+    _check(oracle, ix.search(queries, 150, precision="bf16"), base, queries, 150, m)  # kprime 208
+    _check(oracle, ix.search(queries, 230, precision="bf16"), base, queries, 230, m)  # bf16 slack does not fit: fp32
+    ix.close()
+
+
+def test_bf16_close_rows_fall_back(ctx, oracle):
+    """Rows closer together than bf16 resolves: the bound check must flag the query."""
+    import needle_amd as na
+
+    rng = np.random.default_rng(7)
+    d = 64
+    centre = rng.standard_normal(d).astype(F)
+    base = rng.standard_normal((5000, d)).astype(F)
+    base[500:900] = centre + (rng.standard_normal((400, d)) * 1e-3).astype(F)
+    queries = np.stack([centre, rng.standard_normal(d).astype(F)])
+    for m in (na.DistanceFunction.Cosine, na.DistanceFunction.Euclidean):
+        ctx.reset_metrics()
+        ix = na.FlatIndex(ctx, base, m)
+        _check(oracle, ix.search(queries, 10, precision="bf16"), base, queries, 10, m)
+        ix.close()
+        assert ctx.metrics()["fallback_queries"] >= 1
+
+
+def test_bf16_ties_masks_and_dimension_beyond_registers(ctx, oracle):
+    import needle_amd as na
+
+    base, queries = _data(5, 2000, 32, 4)
+    base[100] = base[7]
+    base[1500] = base[7]
+    queries[0] = base[7]
+    m = na.DistanceFunction.Euclidean
+    ix = na.FlatIndex(ctx, base, m)
+    got = ix.search(queries, 6, precision="bf16")
+    _check(oracle, got, base, queries, 6, m)
+    assert got[0][0, :3].tolist() == [7, 100, 1500]
+    none = np.zeros(2000, dtype=bool)
+    assert ix.search(queries, 5, precision="bf16", filter_mask=none)[2].tolist() == [0] * 4
+    ix.close()
+    base, queries = _data(6, 1500, 1000, 9)  # wider than the bf16 kernel holds: served by the fp32 scan
+    ix = na.FlatIndex(ctx, base, na.DistanceFunction.Cosine)
+    _check(oracle, ix.search(queries, 5, precision="bf16"), base, queries, 5, na.DistanceFunction.Cosine)
+    ix.close()
