@@ -102,6 +102,7 @@ typedef struct needle_hip_metrics {
     double scan_ms_total;         /* device time of those launches (needs profiling on) */
     double last_scan_ms;
     double last_search_ms;        /* device time of the last whole search (profiling on) */
+    uint64_t refined_queries;     /* queries a bf16 first pass left undecided, re-run with the fp32 first pass */
 } needle_hip_metrics;
 
 /* ---- context --------------------------------------------------------- */

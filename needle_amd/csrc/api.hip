@@ -132,7 +132,7 @@ void nh::index_free(needle_hip_index* ix) {
     for (DevBuf* b : {&ix->w_qraw, &ix->w_qop, &ix->w_qn2, &ix->w_lists, &ix->w_lcnt, &ix->w_cand, &ix->w_candn,
                       &ix->w_tau, &ix->w_flagged, &ix->w_flagcnt, &ix->w_filter, &ix->w_premax, &ix->w_tau0, &ix->x_keys, &ix->x_u32,
                       &ix->x_u64, &ix->x_sel, &ix->x_mask, &ix->v_probe_ids, &ix->v_probe_d, &ix->v_probe_n, &ix->v_probe32,
-                      &ix->v_items, &ix->v_itemq})
+                      &ix->v_items, &ix->v_itemq, &ix->r_idx, &ix->r_q, &ix->r_ids, &ix->r_dists, &ix->r_cnt})
         b->release();
     delete ix;
 }
@@ -565,6 +565,27 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     }
     if (n_flagged > 0) {
         if (n_flagged > q) n_flagged = q;
+        if (bf16) {
+            // The bf16 scores could not separate these queries' k-th hit from the rows left out: give them
+            // the fp32 first pass (whose own leftovers go to the exact scan) and put the answers in place.
+            HIP_TRY(ix->r_idx.ensure((size_t)n_flagged * sizeof(uint32_t)));
+            HIP_TRY(ix->r_q.ensure((size_t)n_flagged * ix->dim * sizeof(float)));
+            HIP_TRY(ix->r_ids.ensure((size_t)n_flagged * k * sizeof(uint64_t)));
+            HIP_TRY(ix->r_dists.ensure((size_t)n_flagged * k * sizeof(float)));
+            HIP_TRY(ix->r_cnt.ensure((size_t)n_flagged * sizeof(uint32_t)));
+            HIP_TRY(hipMemcpyAsync(ix->r_idx.p, pp.flagged, (size_t)n_flagged * sizeof(uint32_t), hipMemcpyDeviceToDevice,
+                                   c->stream));
+            HIP_TRY(launch_gather_rows(d_queries, ix->r_idx.as<uint32_t>(), n_flagged, ix->dim, ix->r_q.as<float>(), c->stream));
+            ST_TRY(flat_search_batch_device(ix, ix->r_q.as<float>(), n_flagged, k, NEEDLE_PRECISION_FP32, d_filter,
+                                            ix->r_ids.as<uint64_t>(), ix->r_dists.as<float>(), ix->r_cnt.as<uint32_t>()));
+            HIP_TRY(launch_scatter_results(ix->r_idx.as<uint32_t>(), n_flagged, k, ix->r_ids.as<uint64_t>(),
+                                           ix->r_dists.as<float>(), ix->r_cnt.as<uint32_t>(), d_out_ids, d_out_dists,
+                                           d_out_counts, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            std::lock_guard<std::mutex> g(c->mu);
+            c->m.refined_queries += n_flagged;
+            return NEEDLE_HIP_OK;
+        }
         ST_TRY(run_exact(ix, d_queries, pp.flagged, n_flagged, k, d_filter, d_out_ids, d_out_dists, d_out_counts));
         HIP_TRY(hipStreamSynchronize(c->stream));
         std::lock_guard<std::mutex> g(c->mu);

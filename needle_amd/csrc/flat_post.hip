@@ -651,4 +651,39 @@ hipError_t launch_fill_empty(uint64_t* d_out_ids, float* d_out_dists, uint32_t* 
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const uint32_t* __restrict__ idx,
+                                                          uint32_t dim, float* __restrict__ dst) {
+    const float* s = src + (uint64_t)idx[blockIdx.x] * dim;
+    float* d = dst + (uint64_t)blockIdx.x * dim;
+    for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x) d[i] = s[i];
+}
+
+hipError_t launch_gather_rows(const float* d_src, const uint32_t* d_idx, uint32_t n, uint32_t dim, float* d_dst,
+                              hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(256), 0, stream, d_src, d_idx, dim, d_dst);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void scatter_results_kernel(const uint32_t* __restrict__ idx, uint32_t k,
+                                                             const uint64_t* __restrict__ ids, const float* __restrict__ dists,
+                                                             const uint32_t* __restrict__ counts, uint64_t* __restrict__ out_ids,
+                                                             float* __restrict__ out_dists, uint32_t* __restrict__ out_counts) {
+    const uint32_t s = blockIdx.x, q = idx[s];
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+        out_ids[(uint64_t)q * k + i] = ids[(uint64_t)s * k + i];
+        out_dists[(uint64_t)q * k + i] = dists[(uint64_t)s * k + i];
+    }
+    if (threadIdx.x == 0) out_counts[q] = counts[s];
+}
+
+hipError_t launch_scatter_results(const uint32_t* d_idx, uint32_t n, uint32_t k, const uint64_t* d_ids, const float* d_dists,
+                                  const uint32_t* d_counts, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
+                                  hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_results_kernel, dim3(n), dim3(64), 0, stream, d_idx, k, d_ids, d_dists, d_counts, d_out_ids,
+                       d_out_dists, d_out_counts);
+    return hipGetLastError();
+}
+
 }  // namespace nh

@@ -180,9 +180,31 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
                                                  0, 0);
         };
 
+        // LDS address of this lane's fragment of k-step 0 of row tile 0 in slot 0: row l31, chunk h ^ (l31 & 15).
+        // K-step kk lives at that address ^ (kk << 5) (the chunk index is XOR-swizzled), row tile 1 at +8192.
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+        const uint32_t frag0 = lds0 + l31 * 256u + (((h ^ l31) & 15u) << 4);
+        // The fragment reads are issued and awaited by hand: with the direct-to-LDS fills always in flight the
+        // compiler would wait for ALL outstanding LDS traffic before every MFMA group.  Fragment sets
+        // rotate: the reads of k-step kk+2 are issued before the MFMAs of k-step kk, and the wait before those
+        // MFMAs leaves the four reads of k-steps kk+1 and kk+2 in flight.  (Four sets, not three: a stage has
+        // 8 k-steps, so the set of k-step kk is kk % 4 in every stage, also across half tile boundaries.)
+        bf16x8 a[4][2];
+        auto read_frags = [&](bf16x8 (&dst)[2], uint32_t slot_, int kk_) {
+            const uint32_t addr = (frag0 + slot_ * BF_STAGE_BYTES) ^ ((uint32_t)kk_ << 5);
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:8192"
+                         : "=&v"(dst[0]), "=&v"(dst[1])
+                         : "v"(addr)
+                         : "memory");
+        };
+
         // prologue: the first PD stages of the block's run (clamped to its last tile: surplus fills are harmless)
 #pragma unroll
         for (int j = 0; j < BF_PD; ++j) issue_stage(min(t0 + (uint32_t)(j / UT), t1 - 1), j % UT, (uint32_t)j);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_inflight_behind<STAGES, CINIT>(0)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(a[0], 0, 0);
+        read_frags(a[1], 0, 1);
 
         f32x16 acc[2][NT];
         uint32_t slot = 0;  // slot of the stage being multiplied
@@ -192,12 +214,6 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
                 static_for<STAGES>([&](auto s_c) {
                     constexpr int s = decltype(s_c)::value;
                     constexpr int u = half * STAGES + s;
-                    // this wave's pieces of the stage have landed; after the barrier everybody's have, and
-                    // everybody is done reading the previous stage's slot
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_inflight_behind<STAGES, CINIT>(u)) : "memory");
-                    __builtin_amdgcn_s_barrier();
-                    issue_stage(min(tile + (uint32_t)((u + BF_PD) / UT), t1 - 1), (u + BF_PD) % UT, (slot + BF_PD) % BF_NBUF);
-                    const unsigned char* As = smem + slot * BF_STAGE_BYTES;
                     if (s == 0) {
                         if (CINIT) {
                             const float* cs = (const float*)(smem + BF_NBUF * BF_STAGE_BYTES + slot * BF_CSLOT + wave * 256u);
@@ -223,29 +239,27 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
                                     for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
                         }
                     }
-                    // fragments of k-step kk+1 are read while the MFMAs of k-step kk run
-                    bf16x8 a[2][2];
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-                        a[0][mt] = __builtin_bit_cast(bf16x8, *(const uint4*)(As + bf_lds_off(mt * 32 + l31, h)));
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        if (kk + 1 < 8) {
-#pragma unroll
-                            for (int mt = 0; mt < 2; ++mt)
-                                a[(kk + 1) & 1][mt] = __builtin_bit_cast(
-                                    bf16x8, *(const uint4*)(As + bf_lds_off(mt * 32 + l31, (kk + 1) * 2 + h)));
+                    static_for<8>([&](auto kk_c) {
+                        constexpr int kk = decltype(kk_c)::value;
+                        constexpr int g = s * 8 + kk;  // k-step within the dimension
+                        if (kk == 5) {
+                            // The NEXT stage: this wave's pieces have landed (the stage after it may be in flight);
+                            // behind the barrier everybody's have, and everybody has left the previous stage, whose
+                            // slot takes the stage three ahead.
+                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_stage_loads<STAGES, CINIT>(u + 2)) : "memory");
+                            __builtin_amdgcn_s_barrier();
+                            issue_stage(min(tile + (uint32_t)((u + BF_PD) / UT), t1 - 1), (u + BF_PD) % UT,
+                                        (slot + BF_PD) % BF_NBUF);
                         }
+                        if (kk + 2 < 8) read_frags(a[(kk + 2) % 4], slot, kk + 2);
+                        else read_frags(a[(kk + 2) % 4], (slot + 1) % BF_NBUF, kk + 2 - 8);  // next stage (junk behind the last)
+                        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[kk % 4][0]), "+v"(a[kk % 4][1])::"memory");
 #pragma unroll
                         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk & 1][mt], bq[nt][s * 8 + kk],
-                                                                                     acc[mt][nt], 0, 0, 0);
-                        if (kk + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 LDS reads
-                        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);             // the k-step's MFMAs
-                    }
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk % 4][mt], bq[nt][g], acc[mt][nt], 0, 0, 0);
+                    });
                     slot = (slot + 1) % BF_NBUF;
                 });
                 // selection behind the half tile

@@ -103,6 +103,7 @@ struct needle_hip_index {
     // per-search workspace (grow-only)
     nh::DevBuf w_qraw, w_qop, w_qn2, w_lists, w_lcnt, w_cand, w_candn, w_tau, w_flagged, w_flagcnt, w_filter, w_premax,
         w_tau0;
+    nh::DevBuf r_idx, r_q, r_ids, r_dists, r_cnt;  // queries a reduced-precision pass could not decide, re-run in fp32
     nh::DevBuf x_keys, x_u32, x_u64, x_sel, x_mask;
     nh::DevBuf v_probe_ids, v_probe_d, v_probe_n, v_probe32, v_items, v_itemq;
 };

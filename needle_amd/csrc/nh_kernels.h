@@ -138,6 +138,13 @@ hipError_t launch_merge_topk(const float* d_dists, const uint64_t* d_ids, const 
                              uint32_t lists, uint32_t q, uint32_t per, uint32_t k, uint64_t* d_out_ids,
                              float* d_out_dists, uint32_t* d_out_counts, hipStream_t stream);
 
+// dst[i] = src[idx[i]] for rows of `dim` floats; and the way back for finished result rows.
+hipError_t launch_gather_rows(const float* d_src, const uint32_t* d_idx, uint32_t n, uint32_t dim, float* d_dst,
+                              hipStream_t stream);
+hipError_t launch_scatter_results(const uint32_t* d_idx, uint32_t n, uint32_t k, const uint64_t* d_ids, const float* d_dists,
+                                  const uint32_t* d_counts, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
+                                  hipStream_t stream);
+
 hipError_t launch_fill_empty(uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, uint32_t q,
                              uint32_t k, hipStream_t stream);
 
