@@ -8,8 +8,15 @@ of per-shard results and the merge).  Inputs are resident in HBM before the time
 index build (upload, norms, operand copy) is outside it, like the reference's insert phase.
 
 Default workload (N=1): exact flat batch_search, 1M x 384 cosine, 10K queries, k=10, synthetic
-unit-normalised Gaussian embeddings.  With --gpus N > 1 the same 1M rows are split into N contiguous
-row blocks (strong scaling), launched by torch.distributed.run, one rank per GPU.
+unit-normalised Gaussian embeddings, bf16 first pass (the delivered ids and distances are those of
+the reference's f32 scalar arithmetic whatever the first pass; the fp32 first pass is timed beside it).
+
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU):
+  --shard queries (default): every GPU holds the whole base (1M x 384 is 1.5 GB of 288 GB) and serves
+      its own 10K queries; no exchange on the data path; per-GPU work is fixed -> weak scaling.
+  --shard rows: the base is split into N contiguous row blocks, every GPU scans its block for ALL
+      queries, per-shard results are all-gathered over RCCL and merged -> strong scaling of one batch;
+      the layout for bases beyond one GPU's memory.
 """
 from __future__ import annotations
 
@@ -41,7 +48,9 @@ def parse():
     ap.add_argument("--queries", type=int, default=10_000)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="cosine")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"])
+    ap.add_argument("--shard", default="queries", choices=["queries", "rows"])
+    ap.add_argument("--secondary-steps", type=int, default=2, help="steps of the other first-pass precision (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per first-pass launch from a separate rocprofv3 --pmc run")
@@ -80,21 +89,30 @@ def main():
     from needle_amd.sharded import ShardedSearcher, hip_local_search, hip_merge
 
     chunk = GEN_CHUNK
-    per = -(-args.rows // world)
-    per = -(-per // chunk) * chunk if world > 1 else per  # keep shard starts on generator chunks
-    lo = min(rank * per, args.rows)
-    hi = min(lo + per, args.rows)
+    by_rows = args.shard == "rows" and world > 1
+    if by_rows:
+        per = -(-args.rows // world)
+        per = -(-per // chunk) * chunk  # keep shard starts on generator chunks
+        lo = min(rank * per, args.rows)
+        hi = min(lo + per, args.rows)
+    else:
+        lo, hi = 0, args.rows
     metric = na.DistanceFunction.from_str(args.metric)
 
     base = synth(hi - lo, args.dim, 42, device, first_row=lo)
-    queries = synth(args.queries, args.dim, 42 + 999_999, device)
+    # query-sharded replicas draw different queries per rank; row shards all serve the same ones
+    queries = synth(args.queries, args.dim, 42 + 999_999 + (0 if by_rows else rank), device)
     torch.cuda.synchronize()
 
     ctx = na.Context(local_rank)
     t_build = time.perf_counter()
     index = na.FlatIndex(ctx, base, metric)
     t_build = time.perf_counter() - t_build
-    searcher = ShardedSearcher(hip_local_search(index, args.precision), hip_merge(ctx), lo)
+    local = {prec: hip_local_search(index, prec) for prec in ("fp32", "bf16")}
+    sharded = {prec: ShardedSearcher(local[prec], hip_merge(ctx), lo) for prec in local} if by_rows else None
+
+    def search(prec):
+        return sharded[prec].search(queries, args.k) if by_rows else local[prec](queries, args.k)
 
     def barrier():
         torch.cuda.synchronize()
@@ -102,36 +120,67 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = searcher.search(queries, args.k)
-    ctx.set_profiling(True)
-    ctx.reset_metrics()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = searcher.search(queries, args.k)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    m = ctx.metrics()
-    ctx.set_profiling(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(prec, steps, warmup):
+        """(elapsed seconds for `steps` searches, library metrics over them, last result)."""
+        out = None
+        for _ in range(warmup):
+            out = search(prec)
+        ctx.set_profiling(True)
+        ctx.reset_metrics()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = search(prec)
+        barrier()
+        el = time.perf_counter() - t0
+        mm = ctx.metrics()
+        ctx.set_profiling(False)
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, mm, out
 
+    def roofline_of(prec, mm):
+        # dominant kernel = first-pass scan: algorithmic flops = 2 * Q * rows_local * dim per launch, over the
+        # launch time the library measures with HIP events on its own stream (seeding pre-pass included)
+        scan_ms = mm["scan_ms_total"] / max(mm["scan_launches"], 1)
+        flops = 2.0 * args.queries * (hi - lo) * args.dim
+        achieved = flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+        peak = FP32_MFMA_PEAK_TFLOPS if prec == "fp32" else BF16_MFMA_PEAK_TFLOPS
+        kernel = "flat_scan_" + ("f32" if prec == "fp32" else "bf16")
+        return {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": measured_traffic(kernel), "launch_ms": round(scan_ms, 3),
+                "launches_per_step": mm["scan_launches"] / max(mm["searches"], 1)}
+
+    def measured_traffic(kernel):
+        """HBM bytes per launch from a separate rocprofv3 --pmc pass over this same workload, if recorded."""
+        if args.traffic_bytes is not None:
+            return args.traffic_bytes
+        try:
+            with open(os.path.join(ROOT, "needle_amd", "measured_traffic.json")) as fh:
+                rec = json.load(fh).get(kernel)
+        except (OSError, ValueError):
+            return None
+        want = {"rows": hi - lo, "dim": args.dim, "queries": args.queries, "k": args.k, "metric": args.metric}
+        if not rec or any(rec.get("workload", {}).get(key) != val for key, val in want.items()):
+            return None
+        return rec["hbm_bytes_per_launch"]
+
+    elapsed, m, out = timed(args.precision, args.steps, args.warmup)
     ids, dists, counts = out
     ms_per_step = elapsed / args.steps * 1e3
-    qps = args.queries * args.steps / elapsed
+    total_queries = args.queries * (1 if by_rows else world)
+    qps = total_queries * args.steps / elapsed
+    roofline = roofline_of(args.precision, m)
 
-    # roofline of the dominant kernel (first-pass scan): algorithmic flops = 2 * Q * rows_local * dim per launch
-    scan_ms = m["scan_ms_total"] / max(m["scan_launches"], 1)
-    flops = 2.0 * args.queries * (hi - lo) * args.dim
-    achieved = flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
-    peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
-    roofline = {"bound": "mfma", "kernel": "flat_scan_" + ("f32" if args.precision == "fp32" else "bf16"),
-                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": args.traffic_bytes, "launch_ms": round(scan_ms, 3),
-                "launches_per_step": m["scan_launches"] / max(args.steps, 1)}
+    secondary = None
+    if args.secondary_steps > 0:
+        other = "fp32" if args.precision == "bf16" else "bf16"
+        el2, m2, _ = timed(other, args.secondary_steps, 1)
+        secondary = {"first_pass": other, "value": round(total_queries * args.secondary_steps / el2, 1),
+                     "unit": "queries/s", "ms_per_step": round(el2 / args.secondary_steps * 1e3, 3),
+                     "roofline": roofline_of(other, m2)}
 
     cpu_baseline = None
     parity = None
@@ -162,14 +211,19 @@ def main():
         line = {
             "metric": "batch-search QPS @ recall@10, 1M & 10M\u00d7384 cosine k=10, 1/2/4/8 MI355X",
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong" if by_rows else "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": f"exact flat batch_search, {args.rows}x{args.dim} {args.metric}, "
                                    f"{args.queries} queries, k={args.k}, unit-normalised Gaussian embeddings",
                        "rows_total": args.rows, "rows_per_gpu": hi - lo, "dim": args.dim, "queries": args.queries,
-                       "k": args.k, "first_pass": args.precision, "sharding": f"row-blocks x{world}",
+                       "k": args.k, "first_pass": args.precision, "queries_total": total_queries,
+                       "sharding": (f"row-blocks x{world}, all-gather + merge" if by_rows
+                                    else f"query-sharded replicas x{world}, no exchange"),
                        "recall_at_10": 1.0 if parity is None or parity["ids_equal"] else None},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
+            "other_first_pass": secondary,
+            "refined_queries_per_step": m["refined_queries"] / max(args.steps, 1),
             "fallback_queries_per_step": m["fallback_queries"] / max(args.steps, 1),
             "index_build_s": round(t_build, 3),
         }

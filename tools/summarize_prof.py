@@ -36,3 +36,31 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
             print("  " + k)
             for c, v in sorted(cs.items()):
                 print(f"      {c:28s} {v:.6g}")
+
+
+# HBM bytes per launch of the first-pass scan kernels: FETCH_SIZE and WRITE_SIZE are in KB; on gfx950
+# FETCH_SIZE tallies the 128-byte requests of wide (16 B per lane) reads at 64 bytes, so it is doubled.
+import json
+
+traffic = {}
+for kern, tag in (("flat_scan_bf16_kernel<0", "flat_scan_bf16"), ("flat_scan_f32_kernel<0", "flat_scan_f32")):
+    fetch = write = 0.0
+    n_f = n_w = 0
+    for sub, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        for f in find(sub, "*counter_collection.csv"):
+            per_dispatch = defaultdict(float)
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    if kern in r.get("Kernel_Name", "") and r.get("Counter_Name") == name:
+                        per_dispatch[r.get("Dispatch_Id")] += float(r.get("Counter_Value", 0) or 0)
+            if per_dispatch:
+                avg = sum(per_dispatch.values()) / len(per_dispatch)
+                if name == "FETCH_SIZE":
+                    fetch, n_f = avg, len(per_dispatch)
+                else:
+                    write, n_w = avg, len(per_dispatch)
+    if n_f and n_w:
+        traffic[tag] = {"hbm_bytes_per_launch": 2.0 * fetch * 1024.0 + write * 1024.0,
+                        "fetch_size_kb": fetch, "write_size_kb": write, "launches": [n_f, n_w]}
+print("== first-pass HBM traffic per launch (FETCH_SIZE x 2 + WRITE_SIZE, bytes)")
+print(json.dumps(traffic, indent=1))
