@@ -155,3 +155,35 @@ def check(status: int) -> None:
     if status == ERR_INVALID_VECTOR:
         raise InvalidVector(status, msg)
     raise NeedleHipError(status, msg)
+
+
+# ---- orderly shutdown --------------------------------------------------------------------------
+# Handles that are still open when the interpreter exits are closed here, indexes before contexts,
+# while the HIP runtime is still loaded; finalizers that run later than this must not call into it.
+import atexit
+import weakref
+
+_live: "weakref.WeakSet" = weakref.WeakSet()
+_shutting_down = False
+
+
+def register_live(obj) -> None:
+    _live.add(obj)
+
+
+def shutting_down() -> bool:
+    return _shutting_down
+
+
+def _close_all() -> None:
+    global _shutting_down
+    objs = list(_live)
+    for o in sorted(objs, key=lambda o: getattr(o, "_close_order", 0)):
+        try:
+            o.close()
+        except Exception:
+            pass
+    _shutting_down = True
+
+
+atexit.register(_close_all)

@@ -3,6 +3,8 @@
 // flat_scan.hip, flat_post.hip and prep.hip.
 #include "nh_api.h"
 
+#include <unordered_set>
+
 using namespace nh;
 
 // ---------------------------------------------------------------------------
@@ -46,6 +48,26 @@ extern "C" int needle_hip_metric_from_str(const char* s) {
     return -1;
 }
 
+// Live handles.  Destroying an index twice, destroying it after its context was shut down, or shutting
+// a context down twice are all harmless: a handle that is not registered any more is left alone, and
+// a context takes the indexes still bound to it along.
+static std::mutex g_reg_mu;
+static std::unordered_set<const void*> g_live_indexes, g_live_contexts;
+
+needle_hip_index* nh::index_new() {
+    needle_hip_index* ix = new (std::nothrow) needle_hip_index();
+    if (ix) {
+        std::lock_guard<std::mutex> g(g_reg_mu);
+        g_live_indexes.insert(ix);
+    }
+    return ix;
+}
+
+static void register_context(needle_hip_ctx* c) {
+    std::lock_guard<std::mutex> g(g_reg_mu);
+    g_live_contexts.insert(c);
+}
+
 extern "C" needle_hip_status needle_hip_init(int device_id, needle_hip_ctx** out_ctx) {
     if (!out_ctx) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "out_ctx is null");
     *out_ctx = nullptr;
@@ -64,6 +86,7 @@ extern "C" needle_hip_status needle_hip_init(int device_id, needle_hip_ctx** out
     if (!c) return fail(NEEDLE_HIP_ERR_OUT_OF_MEMORY, "host allocation failed");
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    register_context(c);
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
     if (e != hipSuccess) {
@@ -76,6 +99,14 @@ extern "C" needle_hip_status needle_hip_init(int device_id, needle_hip_ctx** out
 
 extern "C" void needle_hip_shutdown(needle_hip_ctx* c) {
     if (!c) return;
+    std::vector<needle_hip_index*> bound;
+    {
+        std::lock_guard<std::mutex> g(g_reg_mu);
+        if (!g_live_contexts.erase(c)) return;
+        for (const void* p : g_live_indexes)
+            if (((const needle_hip_index*)p)->ctx == c) bound.push_back((needle_hip_index*)p);
+    }
+    for (needle_hip_index* ix : bound) nh::index_free(ix);  // (a nested centroid index may already be gone: no-op)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& b : c->scratch) b.release();
@@ -111,6 +142,10 @@ extern "C" needle_hip_status needle_hip_reset_metrics(needle_hip_ctx* c) {
 // ---------------------------------------------------------------------------
 void nh::index_free(needle_hip_index* ix) {
     if (!ix) return;
+    {
+        std::lock_guard<std::mutex> g(g_reg_mu);
+        if (!g_live_indexes.erase(ix)) return;
+    }
     (void)hipSetDevice(ix->ctx->device);
     (void)hipStreamSynchronize(ix->ctx->stream);
     if (ix->centroids) nh::index_free(ix->centroids);
@@ -214,7 +249,7 @@ static needle_hip_status flat_alloc(needle_hip_ctx* c, uint64_t n, uint32_t dim,
         return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "the accelerator arithmetic covers cosine, euclidean and dot product only");
     if (n >= 0xfffffff0ull - TILE_ROWS) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "at most 2^32-272 rows per index");
     HIP_TRY(hipSetDevice(c->device));
-    needle_hip_index* ix = new (std::nothrow) needle_hip_index();
+    needle_hip_index* ix = index_new();
     if (!ix) return fail(NEEDLE_HIP_ERR_OUT_OF_MEMORY, "host allocation failed");
     ix->ctx = c;
     ix->n = n;
@@ -599,7 +634,6 @@ static needle_hip_status search_device_locked(needle_hip_index* ix, const float*
                                               uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts) {
     needle_hip_ctx* c = ix->ctx;
     const uint32_t k = params->k;
-    if (k > K_MAX) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "k = %u exceeds the supported maximum %d", k, K_MAX);
     const int precision = params->precision;
     if (precision < NEEDLE_PRECISION_FP32 || precision > NEEDLE_PRECISION_EXACT_SCAN)
         return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "unknown precision %d", precision);

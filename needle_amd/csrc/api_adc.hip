@@ -15,7 +15,7 @@ extern "C" needle_hip_status needle_hip_pq_build(needle_hip_ctx* c, const uint8_
     if (n > 0 && !codes) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "codes is null");
     if (n >= 0xfffffff0ull) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "too many rows");
     HIP_TRY(hipSetDevice(c->device));
-    needle_hip_index* ix = new (std::nothrow) needle_hip_index();
+    needle_hip_index* ix = index_new();
     if (!ix) return fail(NEEDLE_HIP_ERR_OUT_OF_MEMORY, "host allocation failed");
     ix->ctx = c;
     ix->kind = KIND_PQ;
@@ -125,7 +125,7 @@ extern "C" needle_hip_status needle_hip_sq8_build(needle_hip_ctx* c, const uint8
         mn2 += (double)min_vals[j] * (double)min_vals[j];
     }
     HIP_TRY(hipSetDevice(c->device));
-    needle_hip_index* ix = new (std::nothrow) needle_hip_index();
+    needle_hip_index* ix = index_new();
     if (!ix) return fail(NEEDLE_HIP_ERR_OUT_OF_MEMORY, "host allocation failed");
     ix->ctx = c;
     ix->kind = KIND_SQ8;

@@ -65,7 +65,7 @@ extern "C" needle_hip_status needle_hip_ivf_build(needle_hip_ctx* c, const float
         ST_TRY(needle_hip_kmeans_assign(c, NEEDLE_ARITH_DISTANCE_RS, base, n, centroids, nlist, dim, assign.data()));
     }
 
-    needle_hip_index* ix = new (std::nothrow) needle_hip_index();
+    needle_hip_index* ix = index_new();
     if (!ix) return fail(NEEDLE_HIP_ERR_OUT_OF_MEMORY, "host allocation failed");
     ix->ctx = c;
     ix->kind = KIND_IVF;

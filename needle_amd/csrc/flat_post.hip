@@ -8,6 +8,10 @@
 #include "nh_kernels.h"
 #include "nh_select.h"
 
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
 namespace nh {
 
 // ---------------------------------------------------------------------------
@@ -487,9 +491,61 @@ __global__ __launch_bounds__(256) void exact_emit_kernel(ExactParams p) {
     if (threadIdx.x == 0) p.out_counts[q] = ke;
 }
 
+// k beyond the in-LDS ranking of exact_emit_kernel: the gathered keys of every slot are sorted in
+// global memory (segmented radix sort, one segment per slot) and emitted in order.
+__global__ void exact_offsets_kernel(uint32_t* __restrict__ off, uint32_t f, uint32_t k) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= f) off[i] = i * k;
+}
+
+__global__ __launch_bounds__(256) void exact_emit_presorted_kernel(ExactParams p, const uint64_t* __restrict__ sorted) {
+    const uint32_t f = blockIdx.y;
+    const uint32_t q = p.qsel ? p.qsel[f] : f;
+    const uint32_t ke = p.k_eff[f];
+    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < p.k; r += gridDim.x * 256) {
+        const uint64_t key = sorted[(uint64_t)f * p.k + r];
+        p.out_ids[(uint64_t)q * p.k + r] = r < ke ? (key & 0xffffffffull) : ~0ull;
+        p.out_dists[(uint64_t)q * p.k + r] = r < ke ? ord2f((uint32_t)(key >> 32)) : INFINITY;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.out_counts[q] = ke;
+}
+
+static hipError_t exact_emit_large_k(const ExactParams& p, hipStream_t stream) {
+    uint64_t* sorted = nullptr;
+    uint32_t* off = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    const size_t total = (size_t)p.f * p.k;
+    hipError_t e = hipMalloc((void**)&sorted, total * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&off, ((size_t)p.f + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(exact_offsets_kernel, dim3((p.f + 256) / 256), dim3(256), 0, stream, off, p.f, p.k);
+        e = rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes, p.sel, sorted, (unsigned int)total, p.f, off, off + 1, 0, 64,
+                                               stream);
+    }
+    if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
+    if (e == hipSuccess)
+        e = rocprim::segmented_radix_sort_keys(tmp, tmp_bytes, p.sel, sorted, (unsigned int)total, p.f, off, off + 1, 0, 64,
+                                               stream);
+    if (e == hipSuccess) {
+        const uint32_t kb = (p.k + 255) / 256 < 1024 ? (p.k + 255) / 256 : 1024;
+        hipLaunchKernelGGL(exact_emit_presorted_kernel, dim3(kb, p.f), dim3(256), 0, stream, p, sorted);
+        e = hipGetLastError();
+    }
+    const hipError_t es = hipStreamSynchronize(stream);  // the temporaries are freed below
+    if (e == hipSuccess) e = es;
+    if (tmp) (void)hipFree(tmp);
+    if (off) (void)hipFree(off);
+    if (sorted) (void)hipFree(sorted);
+    return e;
+}
+
 hipError_t launch_exact_scan(const ExactParams& p, hipStream_t stream) {
     if (p.f == 0) return hipSuccess;
     hipError_t e;
+    if (p.k > (uint32_t)K_MAX) {  // unused selection slots must sort behind every real key
+        if ((e = hipMemsetAsync(p.sel, 0xff, sizeof(uint64_t) * (size_t)p.f * p.k, stream)) != hipSuccess) return e;
+    }
     if ((e = hipMemsetAsync(p.live, 0, sizeof(uint32_t) * p.f, stream)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(p.hist, 0, sizeof(uint32_t) * 256 * p.f, stream)) != hipSuccess) return e;
     const uint32_t nb = (p.n + 255) / 256;
@@ -502,6 +558,7 @@ hipError_t launch_exact_scan(const ExactParams& p, hipStream_t stream) {
         hipLaunchKernelGGL(exact_pick_kernel, dim3(fb), dim3(64), 0, stream, p, shift);
     }
     hipLaunchKernelGGL(exact_gather_kernel, dim3(hb, p.f), dim3(256), 0, stream, p);
+    if (p.k > (uint32_t)K_MAX) return exact_emit_large_k(p, stream);
     hipLaunchKernelGGL(exact_emit_kernel, dim3(p.f), dim3(256), 0, stream, p);
     return hipGetLastError();
 }

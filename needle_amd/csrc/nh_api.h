@@ -119,6 +119,7 @@ needle_hip_status run_exact(needle_hip_index* ix, const float* d_queries, const 
                             uint32_t* d_out_counts, const uint32_t* d_probe = nullptr,
                             const uint32_t* d_probe_n = nullptr, uint32_t nprobe = 0);
 uint32_t choose_kprime(uint32_t k, int precision);
+needle_hip_index* index_new();  // registered as live; null when out of host memory
 void index_free(needle_hip_index* ix);
 needle_hip_status finish_operands(needle_hip_index* ix, bool validate);
 needle_hip_status upload_mask(needle_hip_index* ix, const uint32_t* mask_host);

@@ -46,15 +46,18 @@ def _mask_words(mask, n):
 class Context:
     """One HIP device (needle_hip_ctx)."""
 
+    _close_order = 1  # at interpreter exit contexts close after the indexes bound to them
+
     def __init__(self, device: int = 0):
         self._h = C.c_void_p()
         _lib.check(_lib.lib().needle_hip_init(device, C.byref(self._h)))
         self.device = device
+        _lib.register_live(self)
 
     def close(self) -> None:
-        if getattr(self, "_h", None) and self._h.value:
+        if getattr(self, "_h", None) and self._h.value and not _lib.shutting_down():
             _lib.lib().needle_hip_shutdown(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):  # pragma: no cover - best effort
         try:
@@ -146,9 +149,9 @@ class FlatIndex:
         return self
 
     def close(self) -> None:
-        if getattr(self, "_h", None) and self._h.value:
+        if getattr(self, "_h", None) and self._h.value and not _lib.shutting_down():
             _lib.lib().needle_hip_index_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):  # pragma: no cover
         try:

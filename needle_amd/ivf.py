@@ -155,9 +155,9 @@ class IvfIndex:
 
     # ---- device index ---------------------------------------------------------
     def close(self) -> None:
-        if self._h.value:
+        if getattr(self, "_h", None) and self._h.value and not _lib.shutting_down():
             _lib.lib().needle_hip_index_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):  # pragma: no cover
         try:

@@ -296,3 +296,32 @@ def test_device_resident_search(ctx, oracle):
     got = (ids.cpu().numpy().view(np.uint64), dists.cpu().numpy(), counts.cpu().numpy().view(np.uint32))
     _check(oracle, got, base, queries, k, m)
     ix.close()
+
+
+def test_k_beyond_the_in_lds_ranking(ctx, oracle):
+    """k in the thousands (clamp_k allows any k <= len): the exact scan sorts its selection in global memory."""
+    import needle_amd as na
+
+    base, queries = _data(9, 6000, 20, 5)
+    m = na.DistanceFunction.Euclidean
+    valid = np.ones(6000, dtype=bool)
+    valid[::7] = False
+    ix = na.FlatIndex(ctx, base, m, valid=valid)
+    for k in (2049, 4000, 6000):
+        _check(oracle, ix.search(queries, k), base, queries, k, m, valid=valid)
+    ix.close()
+
+
+def test_handles_outliving_their_context(oracle):
+    """Destroying an index after its context is shut down, or twice, is harmless."""
+    import needle_amd as na
+
+    c = na.Context(0)
+    base, queries = _data(10, 500, 8, 2)
+    ix = na.FlatIndex(c, base, na.DistanceFunction.Cosine)
+    ix2 = na.FlatIndex(c, base, na.DistanceFunction.Euclidean)
+    ix2.close()
+    ix2.close()
+    c.close()  # takes ix along
+    ix.close()
+    c.close()

@@ -1,0 +1,205 @@
+"""The operator mirror (`GpuAccelerator`, `GpuResidentIndex`), the collection mirror and the shard
+merge, through the C ABI, against the oracle's restatement of the reference's CPU arm
+(src/experimental/gpu/common.rs:515-581 arithmetic, gpu/mod.rs operators) and of
+Collection::batch_search (src/collection/batch.rs).  Ids bit-exact, distances bit-equal."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+F = np.float32
+U64MAX = np.iinfo(np.uint64).max
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import needle_amd as na
+
+    c = na.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def accel(ctx):
+    from needle_amd.accelerator import GpuAccelerator
+
+    return GpuAccelerator(ctx=ctx)
+
+
+def _bits(a):
+    return np.asarray(a, dtype=F).view(np.uint32)
+
+
+@pytest.mark.parametrize("dim", [3, 16, 130, 384])
+def test_batch_distance_operators(accel, oracle, dim):
+    rng = np.random.default_rng(dim)
+    base = rng.standard_normal((777, dim)).astype(F)
+    q = rng.standard_normal(dim).astype(F)
+    base[5] = 0.0  # zero row: cosine distance 1.0 (gpu/common.rs cosine guard)
+    for fn, dt in ((accel.batch_cosine_distance, oracle.ACCEL_COSINE), (accel.batch_euclidean_distance, oracle.ACCEL_EUCLIDEAN),
+                   (accel.batch_dot_product, oracle.ACCEL_DOT)):
+        got = fn(q, base)
+        want = oracle.accel_batch_distance(q, base, dt)
+        assert np.array_equal(_bits(got), _bits(want)), (dt, got[:4], want[:4])
+    assert accel.batch_cosine_distance(q, np.zeros((0, dim), dtype=F)).size == 0  # gpu/mod.rs:315-317
+    import needle_amd as na
+
+    with pytest.raises(na.DimensionMismatch):
+        accel.batch_cosine_distance(q, [list(range(dim + 1))])
+
+
+@pytest.mark.parametrize("dt_name", ["Cosine", "Euclidean", "DotProduct"])
+def test_fused_and_batch_fused_search(accel, oracle, dt_name):
+    from needle_amd.distance import DistanceType
+
+    dt = DistanceType[dt_name]
+    rng = np.random.default_rng(int(dt) + 10)
+    base = rng.standard_normal((6000, 70)).astype(F)
+    queries = rng.standard_normal((33, 70)).astype(F)
+    oi, od, oc = oracle.accel_batch_fused_search(queries, base, 10, int(dt))
+    got = accel.batch_fused_search(queries, base, 10, dt)
+    assert len(got) == 33
+    for i, hits in enumerate(got):
+        assert [h[0] for h in hits] == oi[i, : oc[i]].tolist()
+        assert np.array_equal(_bits([h[1] for h in hits]), _bits(od[i, : oc[i]]))
+    one = accel.fused_search(queries[0], base, 7, dt)
+    si, sd = oracle.accel_fused_search(queries[0], base, 7, int(dt))
+    assert [h[0] for h in one] == si.tolist() and np.array_equal(_bits([h[1] for h in one]), _bits(sd))
+    assert accel.batch_fused_search([], base, 5, dt) == [] and accel.batch_fused_search(queries, [], 5, dt) == []
+    big = accel.fused_search(queries[1], base[:4], 10, dt)  # k > n
+    assert len(big) == 4
+
+
+def test_streaming_and_prefiltered_search(accel, oracle):
+    from needle_amd.distance import DistanceType
+
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((5000, 48)).astype(F)
+    q = rng.standard_normal(48).astype(F)
+    for chunk in (64, 1000, 10000):  # the reference merges per-chunk top-k lists: same set as one search
+        si, sd = oracle.accel_streaming_search(q, base, 9, oracle.ACCEL_EUCLIDEAN, chunk)
+        got = accel.streaming_batch_search(q, base, 9, DistanceType.Euclidean, chunk_size=chunk)
+        assert [h[0] for h in got] == si.tolist() and np.array_equal(_bits([h[1] for h in got]), _bits(sd))
+    # prefiltered: (original index, vector) pairs, predicate on the original index (gpu/mod.rs:1033-1080)
+    pairs = [(1000 + 3 * i, base[i]) for i in range(2000)]
+    keep = lambda idx: idx % 2 == 0  # noqa: E731
+    got = accel.prefiltered_batch_search(q, pairs, 5, DistanceType.Cosine, keep)
+    kept = [(idx, v) for idx, v in pairs if keep(idx)]
+    si, sd = oracle.accel_fused_search(q, np.stack([v for _, v in kept]), 5, oracle.ACCEL_COSINE)
+    assert [h[0] for h in got] == [kept[int(j)][0] for j in si]
+    assert np.array_equal(_bits([h[1] for h in got]), _bits(sd))
+    assert accel.prefiltered_batch_search(q, pairs, 5, DistanceType.Cosine, lambda idx: False) == []
+
+
+def test_kmeans_assign(accel, oracle):
+    rng = np.random.default_rng(4)
+    vecs = rng.standard_normal((9000, 40)).astype(F)
+    cents = rng.standard_normal((300, 40)).astype(F)
+    cents[17] = cents[3]  # equal centroids: the first one wins (gpu/mod.rs:660-703 strict <)
+    got = accel.kmeans_assign(vecs, cents)
+    want = oracle.accel_kmeans_assign(vecs, cents)
+    assert got == want.tolist()
+
+
+def test_merge_topk_device(ctx, oracle):
+    import torch
+
+    rng = np.random.default_rng(5)
+    lists, q, per, k = 4, 50, 12, 10
+    dists = np.sort(rng.random((lists, q, per)).astype(F), axis=2)
+    ids = rng.permutation(lists * q * per).reshape(lists, q, per).astype(np.uint64)
+    counts = rng.integers(0, per + 1, size=(lists, q)).astype(np.uint32)
+    dists[1, :, 0] = dists[0, :, 0]  # cross-shard distance ties: the lower id wins
+    dev = torch.device("cuda", 0)
+    td = torch.from_numpy(dists).to(dev)
+    ti = torch.from_numpy(ids.view(np.int64)).to(dev)
+    tc = torch.from_numpy(counts.view(np.int32)).to(dev)
+    oi = torch.empty((q, k), dtype=torch.int64, device=dev)
+    od = torch.empty((q, k), dtype=torch.float32, device=dev)
+    oc = torch.empty((q,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.merge_topk_device(td, ti, tc, lists, q, per, k, oi, od, oc)
+    gi, gd, gc = oi.cpu().numpy().view(np.uint64), od.cpu().numpy(), oc.cpu().numpy()
+    for j in range(q):
+        wi, wd = oracle.merge_topk(dists[:, j, :], ids[:, j, :], counts[:, j], k)
+        assert gc[j] == wi.size
+        assert np.array_equal(gi[j, : wi.size], wi) and np.array_equal(_bits(gd[j, : wi.size]), _bits(wd))
+        assert np.all(gi[j, wi.size:] == U64MAX)
+
+
+def test_resident_index(ctx, oracle):
+    from needle_amd.accelerator import GpuResidentIndex
+    from needle_amd.distance import DistanceType
+    import needle_amd as na
+
+    rng = np.random.default_rng(6)
+    rows = rng.standard_normal((400, 24)).astype(F)
+    ix = GpuResidentIndex(24, DistanceType.Euclidean, ctx=ctx)
+    assert ix.search(rows[0], 5) == []  # empty index
+    ix.add_batch([(10_000 + i, rows[i]) for i in range(400)])
+    assert len(ix) == 400 and ix.dirty
+    q = rng.standard_normal(24).astype(F)
+    si, sd = oracle.accel_fused_search(q, rows, 6, oracle.ACCEL_EUCLIDEAN)
+    got = ix.search(q, 6)
+    assert not ix.dirty
+    assert [h[0] for h in got] == [10_000 + int(j) for j in si] and np.array_equal(_bits([h[1] for h in got]), _bits(sd))
+    assert ix.remove(10_000 + int(si[0])) and not ix.remove(5)
+    keep = np.ones(400, dtype=bool)
+    keep[int(si[0])] = False
+    ids_left = np.flatnonzero(keep)
+    si2, sd2 = oracle.accel_fused_search(q, rows[keep], 6, oracle.ACCEL_EUCLIDEAN)
+    got = ix.search(q, 6)
+    assert [h[0] for h in got] == [10_000 + int(ids_left[int(j)]) for j in si2]
+    with pytest.raises(na.DimensionMismatch):
+        ix.add(1, rows[0][:5])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_collection_batch_search(ctx, oracle, precision):
+    import needle_amd as na
+    from needle_amd.collection import Collection
+
+    rng = np.random.default_rng(7)
+    n, dim = 3000, 64
+    rows = rng.standard_normal((n, dim)).astype(F)
+    col = Collection("docs", dim, na.DistanceFunction.Cosine, ctx=ctx, precision=precision)
+    for i in range(n):
+        col.insert(f"doc{i}", rows[i], {"group": i % 5})
+    queries = rng.standard_normal((17, dim)).astype(F)
+    oi, od, oc = oracle.flat_batch_search(queries, rows, 10, int(na.DistanceFunction.Cosine))
+    res = col.batch_search(queries, 10)
+    for i, hits in enumerate(res):
+        assert [h.id for h in hits] == [f"doc{int(j)}" for j in oi[i, : oc[i]]]
+        assert np.array_equal(_bits([h.distance for h in hits]), _bits(od[i, : oc[i]]))
+        assert all(h.metadata == {"group": int(h.id[3:]) % 5} for h in hits)
+    # deletes are tombstones: the row stays resident and is masked (collection delete + search filter)
+    gone = {int(j) for j in oi[:, 0]}
+    for j in gone:
+        assert col.delete(f"doc{j}")
+    assert not col.delete("doc-missing") and len(col) == n - len(gone)
+    valid = np.ones(n, dtype=bool)
+    valid[list(gone)] = False
+    oi, od, oc = oracle.flat_batch_search(queries, rows, 10, int(na.DistanceFunction.Cosine), valid=valid)
+    res = col.batch_search(queries, 10)
+    for i, hits in enumerate(res):
+        assert [h.id for h in hits] == [f"doc{int(j)}" for j in oi[i, : oc[i]]]
+    # metadata pre-filter (batch_search_with_filter, batch.rs:108-171)
+    filt = (np.arange(n) % 5) == 2
+    oi, od, oc = oracle.flat_batch_search(queries, rows, 8, int(na.DistanceFunction.Cosine), valid=valid, filt=filt)
+    res = col.batch_search_with_filter(queries, 8, lambda m: m is not None and m["group"] == 2)
+    for i, hits in enumerate(res):
+        assert [h.id for h in hits] == [f"doc{int(j)}" for j in oi[i, : oc[i]]]
+        assert np.array_equal(_bits([h.distance for h in hits]), _bits(od[i, : oc[i]]))
+    # validation: the whole batch is rejected before any search runs (batch.rs:40-47)
+    bad = queries.copy()
+    bad[3, 5] = np.nan
+    with pytest.raises(na.InvalidVector, match="NaN at index 5"):
+        col.batch_search(bad, 5)
+    with pytest.raises(na.DimensionMismatch, match="expected 64, got 10"):
+        col.batch_search([list(range(10))], 5)
+    with pytest.raises(ValueError):
+        col.insert("doc1", rows[1])
+    assert col.batch_search(queries, 0) == [[] for _ in range(17)]
+    assert col.batch_search([], 5) == []
+    assert len(col.search(queries[0], 10_000)) == len(col)  # clamp_k
