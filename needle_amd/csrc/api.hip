@@ -550,7 +550,26 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
         HIP_TRY(launch_flat_prepass(precision, sp, ix->w_tau0.as<float>(), c->stream));
         sp.tau0 = ix->w_tau0.as<float>();
     }
-    HIP_TRY(launch_flat_scan(precision, sp, c->stream));
+    sp.tile_off = 0;
+    sp.tile_len = plan.tiles_per_split;
+    sp.resume = 0;
+    // Long slices are scanned in three launches of growing length: the thresholds of each are refreshed from
+    // everything listed before it, so that the rows listed per query stay near kseed * ln(rows / sample).
+    uint32_t stages[3] = {plan.tiles_per_split, 0, 0};
+    if (bf16 && seeded && plan.tiles_per_split >= 96 && !(sp.debug & 4u)) {
+        stages[0] = std::max<uint32_t>(3 * pre_tiles, plan.tiles_per_split / 10);
+        stages[1] = plan.tiles_per_split / 4;
+        stages[2] = plan.tiles_per_split - stages[0] - stages[1];
+    }
+    for (int r = 0; r < 3 && stages[r] > 0; ++r) {
+        if (r > 0) {
+            HIP_TRY(launch_tau_refresh(sp, n_lists, ix->w_tau0.as<float>(), c->stream));
+            sp.resume = 1;
+        }
+        sp.tile_len = stages[r];
+        HIP_TRY(launch_flat_scan(precision, sp, c->stream));
+        sp.tile_off += stages[r];
+    }
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     if (sp.debug & 8u) {  // development: how many candidates did the first pass list?
         std::vector<uint32_t> lc((size_t)q_pad * n_lists);

@@ -241,6 +241,52 @@ __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
     if (h == 0 && q_live) p.list_counts[list_idx] = cnt;
 }
 
+// One wave per query, between two launches that share candidate lists: with at least kseed candidates listed,
+// the kseed-th largest listed score is a threshold that kseed live rows reach; the next launch starts from it.
+__global__ __launch_bounds__(64) void tau_refresh_kernel(const uint2* __restrict__ lists, const uint32_t* __restrict__ counts,
+                                                         uint32_t n_lists, uint32_t cap, uint32_t kprime, uint32_t kseed,
+                                                         float* __restrict__ tau) {
+    constexpr uint32_t MAXE = 1024;  // more listed than this: keep the threshold (the lists are long anyway)
+    __shared__ uint32_t ord[MAXE];
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    uint32_t total = 0;
+    for (uint32_t l0 = 0; l0 < n_lists; l0 += 64) {
+        const uint32_t li = l0 + lane;
+        const uint32_t c = li < n_lists ? min(counts[(uint64_t)q * n_lists + li], kprime) : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
+            if (lane >= (uint32_t)off) incl += t;
+        }
+        const uint32_t dst = total + incl - c;
+        const uint2* l = lists + ((uint64_t)q * n_lists + li) * cap;
+        for (uint32_t i = 0; i < c; ++i)
+            if (dst + i < MAXE) ord[dst + i] = f2ord(__uint_as_float(l[i].x));
+        total += (uint32_t)__shfl((int)incl, 63);
+    }
+    __syncthreads();
+    if (total < kseed || total > MAXE) return;
+    uint32_t prefix = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t trial = prefix | (1u << bit);
+        uint32_t cnt = 0;
+        for (uint32_t i = 0; i < total; i += 64) {
+            const bool ge = (i + lane < total) && (ord[i + lane] >= trial);
+            cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ge));
+        }
+        if (cnt >= kseed) prefix = trial;
+    }
+    if (lane == 0) tau[q] = fmaxf(tau[q], ord2f(prefix));
+}
+
+hipError_t launch_tau_refresh(const ScanParams& p, uint32_t n_lists, float* d_tau, hipStream_t stream) {
+    if (p.n_queries == 0) return hipSuccess;
+    hipLaunchKernelGGL(tau_refresh_kernel, dim3(p.n_queries), dim3(64), 0, stream, p.lists, p.list_counts, n_lists, p.cap,
+                       p.kprime, p.kseed, d_tau);
+    return hipGetLastError();
+}
+
 // One wave per query: tau0 = (kprime-th largest of the query's group maxima) - 2 ulps.
 __global__ __launch_bounds__(64) void tau0_kernel(const float* __restrict__ pre_max, uint32_t groups,
                                                   uint32_t kprime, float* __restrict__ tau0) {

@@ -122,9 +122,14 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
         q_tile = blockIdx.x % p.q_tiles;
     }
     const uint32_t q0 = q_tile * QB + wave * (32 * NT);  // first query of this wave
-    const uint32_t t0 = split * p.tiles_per_split;
+    uint32_t t0 = split * p.tiles_per_split;
     uint32_t t1 = min(t0 + p.tiles_per_split, p.n_tiles);
-    if (MODE == MODE_PRE) t1 = min(t1, t0 + p.pre_tiles);
+    if (MODE == MODE_PRE) {
+        t1 = min(t1, t0 + p.pre_tiles);
+    } else {
+        t0 = min(t0 + p.tile_off, t1);
+        t1 = min(t0 + p.tile_len, t1);
+    }
 
     float tau[NT];
     uint32_t cnt[NT], list_idx[NT];
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
         tau[nt] = -INFINITY;
         if (MODE != MODE_PRE && p.tau0) tau[nt] = p.tau0[my_query];
         if ((p.debug & 1u) || my_query >= p.n_queries) tau[nt] = INFINITY;
-        cnt[nt] = 0;
+        cnt[nt] = (MODE != MODE_PRE && p.resume) ? p.list_counts[list_idx[nt]] : 0u;
 #pragma unroll
         for (int g = 0; g < 4; ++g) gmax[nt][g] = -INFINITY;
     }
@@ -339,8 +344,10 @@ static hipError_t launch_bf16_mode(const ScanParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_flat_scan_bf16(const ScanParams& p, bool prepass, hipStream_t stream) {
-    if (p.n_splits * p.q_tiles == 0) return hipSuccess;
+hipError_t launch_flat_scan_bf16(const ScanParams& p0, bool prepass, hipStream_t stream) {
+    if (p0.n_splits * p0.q_tiles == 0) return hipSuccess;
+    ScanParams p = p0;
+    if (p.tile_len == 0) { p.tile_off = 0; p.tile_len = p.tiles_per_split; }  // unset: the whole slice
     if (p.cinit)
         return prepass ? launch_bf16_mode<MODE_PRE, true>(p, stream) : launch_bf16_mode<MODE_FLAT, true>(p, stream);
     return prepass ? launch_bf16_mode<MODE_PRE, false>(p, stream) : launch_bf16_mode<MODE_FLAT, false>(p, stream);

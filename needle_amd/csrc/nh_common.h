@@ -89,6 +89,9 @@ struct ScanParams {
     const float* tau0;        // [q_pad] starting threshold of the main pass, or null
     uint32_t pre_tiles;
     uint32_t kseed;           // rank of the seeded threshold among the sampled group maxima (k <= kseed <= kprime)
+    // a launch may cover only tiles [tile_off, tile_off + tile_len) of every slice; `resume` continues the
+    // candidate lists of the launch before it (counts are read back), with thresholds refreshed in between
+    uint32_t tile_off, tile_len, resume;
     // inverted-list scan: one workgroup per work item = (one list's row tiles) x (<= 128 of the
     // queries probing that list); rows are positions in the list-ordered copy of the base
     const IvfItem* items;     // [grid]

@@ -8,6 +8,8 @@ namespace nh {
 hipError_t launch_flat_scan(int precision, const ScanParams& p, hipStream_t stream);
 // pre-pass over p.pre_tiles tiles per slice (writes p.pre_max), then d_tau0[q_pad]
 hipError_t launch_flat_prepass(int precision, const ScanParams& p, float* d_tau0, hipStream_t stream);
+// between two launches sharing lists: d_tau[q] = max(d_tau[q], kseed-th largest score listed for q so far)
+hipError_t launch_tau_refresh(const ScanParams& p, uint32_t n_lists, float* d_tau, hipStream_t stream);
 // inverted-list scan: one workgroup per p.items[i]
 hipError_t launch_ivf_scan(int precision, const ScanParams& p, uint32_t n_items, hipStream_t stream);
 int flat_scan_blocks_per_cu(int precision);
