@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libneedle_hip.so")
+# NEEDLE_HIP_LIBRARY names another build of the same library (kernel development: A/B runs in one job)
+LIB_PATH = os.environ.get("NEEDLE_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libneedle_hip.so")
 
 # needle_hip_status
 OK, ERR_DIMENSION_MISMATCH, ERR_INVALID_VECTOR, ERR_INVALID_ARGUMENT, ERR_OUT_OF_MEMORY, ERR_HIP, ERR_NOT_TRAINED, \

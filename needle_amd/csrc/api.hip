@@ -571,6 +571,20 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
         sp.tile_off += stages[r];
     }
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    if (sp.debug & 64u) {  // development, with a BF_STAMP build: in-kernel clock of the last launch
+        const uint32_t nb = plan.n_splits * q_tiles;
+        std::vector<uint64_t> st((size_t)nb * 2);
+        HIP_TRY(hipMemcpyAsync(st.data(), ix->w_premax.p, st.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::vector<double> ghz;
+        double cyc = 0;
+        for (uint32_t b = 0; b < nb; ++b)
+            if (st[2 * b + 1]) { ghz.push_back((double)st[2 * b] / (double)st[2 * b + 1] * 0.1); cyc += (double)st[2 * b]; }
+        std::sort(ghz.begin(), ghz.end());
+        if (!ghz.empty())
+            fprintf(stderr, "[needle_hip] in-kernel clock: median %.3f GHz (min %.3f, max %.3f), mean block cycles %.0f\n",
+                    ghz[ghz.size() / 2], ghz.front(), ghz.back(), cyc / ghz.size());
+    }
     if (sp.debug & 8u) {  // development: how many candidates did the first pass list?
         std::vector<uint32_t> lc((size_t)q_pad * n_lists);
         HIP_TRY(hipMemcpyAsync(lc.data(), sp.list_counts, lc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));

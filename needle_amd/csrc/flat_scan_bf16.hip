@@ -40,6 +40,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
+#ifndef BF_FILL_KK
+#define BF_FILL_KK 4      // k-step of a stage at which the fills of the stage three ahead start
+#endif
+#ifndef BF_FILL_SPREAD
+#define BF_FILL_SPREAD 1  // 1: one fill piece per k-step from BF_FILL_KK on; 0: all four at BF_FILL_KK
+#endif
+#ifndef BF_READ_AHEAD
+#define BF_READ_AHEAD 2   // fragment reads run this many k-steps ahead of the MFMAs (2 or 3)
+#endif
+
 constexpr int BF_ROWS = 64;                               // rows per stage: half a 128-row tile
 constexpr int BF_BK = 128;                                // dims per stage
 constexpr int BF_STAGE_BYTES = BF_ROWS * BF_BK * 2;       // 16 KB
@@ -146,6 +156,10 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
         for (int g = 0; g < 4; ++g) gmax[nt][g] = -INFINITY;
     }
 
+#ifdef BF_STAMP
+    // diagnostic build only: shader-clock and 100 MHz real-time stamps around the block's run
+    const uint64_t st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (t1 > t0) {  // block-uniform
         // stationary query fragments: lane (l31, h) holds dims 16*ks + 8*h .. +7 of query q0 + 32*nt + l31
         bf16x8 bq[NT][KS];
@@ -154,13 +168,15 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
         for (int nt = 0; nt < NT; ++nt) {
             const uint16_t* qrow = gB + (uint64_t)(q0 + nt * 32 + l31) * p.dpad + 8 * h;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                bq[nt][ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(qrow + ks * 16));
-                // keep the fragment in the accumulation half of the register file: the MFMA reads its B
-                // operand from there directly, and the other half stays free for the row fragments
-                asm volatile("" : "+a"(bq[nt][ks]));
-            }
+            for (int ks = 0; ks < KS; ++ks) bq[nt][ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(qrow + ks * 16));
         }
+        // keep the fragments in the accumulation half of the register file: the MFMA reads its B operand from
+        // there directly, and the other half stays free for the row fragments (pinned after ALL loads were
+        // issued, so that the loads overlap)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(bq[nt][ks]));
 
         const unsigned char* __restrict__ gA = (const unsigned char*)p.base_op;
         const uint32_t row_bytes = p.dpad * 2;
@@ -171,18 +187,21 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
             const uint32_t r = (wave * 4 + i) * 4 + (lane >> 4), cphys = lane & 15;
             src_off[i] = r * row_bytes + ((cphys ^ (r & 15u)) << 4);
         }
-        // fill slot `slot` with stage u (0 .. UT-1) of tile `tile` (tile clamped by the caller)
-        auto issue_stage = [&](uint32_t tile, int u, uint32_t slot) {
+        // fill slot `slot` with stage u (0 .. UT-1) of tile `tile` (tile clamped by the caller); piece i = 0..3, or
+        // all four.  The accumulator seeds of a half tile travel with piece 3 of its first stage.
+        auto issue_piece = [&](uint32_t tile, int u, uint32_t slot, int i) {
             const uint32_t half = (uint32_t)(u / STAGES), s2 = (uint32_t)(u % STAGES);
             const unsigned char* src = gA + (uint64_t)(tile * TILE_ROWS + half * BF_ROWS) * row_bytes + s2 * 256u;
             unsigned char* dst = smem + slot * BF_STAGE_BYTES + wave * 4096u;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_global_load_lds((glb_void*)(src + src_off[i]), (lds_void*)(dst + i * 1024), 16, 0, 0);
-            if (CINIT && s2 == 0)
+            __builtin_amdgcn_global_load_lds((glb_void*)(src + src_off[i]), (lds_void*)(dst + i * 1024), 16, 0, 0);
+            if (CINIT && s2 == 0 && i == 3)
                 __builtin_amdgcn_global_load_lds((glb_void*)(p.cinit + (uint64_t)tile * TILE_ROWS + half * BF_ROWS + lane),
                                                  (lds_void*)(smem + BF_NBUF * BF_STAGE_BYTES + slot * BF_CSLOT + wave * 256u), 4,
                                                  0, 0);
+        };
+        auto issue_stage = [&](uint32_t tile, int u, uint32_t slot) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) issue_piece(tile, u, slot, i);
         };
 
         // LDS address of this lane's fragment of k-step 0 of row tile 0 in slot 0: row l31, chunk h ^ (l31 & 15).
@@ -208,8 +227,8 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
         for (int j = 0; j < BF_PD; ++j) issue_stage(min(t0 + (uint32_t)(j / UT), t1 - 1), j % UT, (uint32_t)j);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_inflight_behind<STAGES, CINIT>(0)) : "memory");
         __builtin_amdgcn_s_barrier();
-        read_frags(a[0], 0, 0);
-        read_frags(a[1], 0, 1);
+#pragma unroll
+        for (int j = 0; j < BF_READ_AHEAD; ++j) read_frags(a[j], 0, j);
 
         f32x16 acc[2][NT];
         uint32_t slot = 0;  // slot of the stage being multiplied
@@ -247,18 +266,28 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
                     static_for<8>([&](auto kk_c) {
                         constexpr int kk = decltype(kk_c)::value;
                         constexpr int g = s * 8 + kk;  // k-step within the dimension
-                        if (kk == 5) {
+                        if (kk == BF_FILL_KK) {
                             // The NEXT stage: this wave's pieces have landed (the stage after it may be in flight);
                             // behind the barrier everybody's have, and everybody has left the previous stage, whose
-                            // slot takes the stage three ahead.
+                            // slot takes the stage three ahead, one piece per k-step from here on.
                             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_stage_loads<STAGES, CINIT>(u + 2)) : "memory");
                             __builtin_amdgcn_s_barrier();
+                        }
+                        if (BF_FILL_SPREAD) {
+                            if (kk >= BF_FILL_KK && kk < BF_FILL_KK + 4)
+                                issue_piece(min(tile + (uint32_t)((u + BF_PD) / UT), t1 - 1), (u + BF_PD) % UT,
+                                            (slot + BF_PD) % BF_NBUF, kk - BF_FILL_KK);
+                        } else if (kk == BF_FILL_KK) {
                             issue_stage(min(tile + (uint32_t)((u + BF_PD) / UT), t1 - 1), (u + BF_PD) % UT,
                                         (slot + BF_PD) % BF_NBUF);
                         }
-                        if (kk + 2 < 8) read_frags(a[(kk + 2) % 4], slot, kk + 2);
-                        else read_frags(a[(kk + 2) % 4], (slot + 1) % BF_NBUF, kk + 2 - 8);  // next stage (junk behind the last)
-                        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[kk % 4][0]), "+v"(a[kk % 4][1])::"memory");
+                        if (kk + BF_READ_AHEAD < 8) read_frags(a[(kk + BF_READ_AHEAD) % 4], slot, kk + BF_READ_AHEAD);
+                        else  // next stage (junk behind the last)
+                            read_frags(a[(kk + BF_READ_AHEAD) % 4], (slot + 1) % BF_NBUF, kk + BF_READ_AHEAD - 8);
+                        asm volatile("s_waitcnt lgkmcnt(%2)"
+                                     : "+v"(a[kk % 4][0]), "+v"(a[kk % 4][1])
+                                     : "n"(2 * BF_READ_AHEAD)
+                                     : "memory");
 #pragma unroll
                         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -293,6 +322,14 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
         // the surplus fills issued behind the last stage must land before the LDS is given back
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+#ifdef BF_STAMP
+    if (MODE == MODE_FLAT && tid == 0 && p.tile_off != 0 && p.tile_off + p.tile_len >= p.tiles_per_split) {
+        const uint64_t st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+        uint64_t* out = (uint64_t*)p.pre_max + (uint64_t)blockIdx.x * 2;
+        out[0] = st_c1 - st_c0;
+        out[1] = st_r1 - st_r0;
+    }
+#endif
 
     if (MODE == MODE_PRE) {
 #pragma unroll
