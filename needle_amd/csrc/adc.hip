@@ -26,7 +26,7 @@ uint32_t pq_scan_queries_per_block(uint32_t m) {
     return std::min<uint32_t>(PQ_QG_MAX, PQ_LDS_BUDGET / per);
 }
 
-__global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
+__global__ __launch_bounds__(64 * PQ_WAVES) void pq_scan_kernel(PqScanParams p) {
     extern __shared__ __attribute__((aligned(16))) float lut[];  // [qg][m][256]
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t split = blockIdx.x, g0 = blockIdx.y * p.qg;
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
 
     // compute_distance_table, quantization.rs:468-494: per entry a sum over the
     // subspace folded from -0.0 in dimension order
-    for (uint32_t idx = tid; idx < p.qg * tbl; idx += 256) {
+    for (uint32_t idx = tid; idx < p.qg * tbl; idx += 64 * PQ_WAVES) {
         const uint32_t g = idx / tbl, rem = idx - g * tbl, s = rem >> 8, c = rem & 255;
         float sum = -0.0f;
         if (g0 + g < p.q) {
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
 
     const uint32_t r0 = split * p.rows_per_split;
     const uint32_t r1 = min(r0 + p.rows_per_split, p.n);
-    const uint32_t lists_per_q = p.n_splits * 4;
+    const uint32_t lists_per_q = p.n_splits * PQ_WAVES;
     float tau[PQ_QG_MAX];      // wave-uniform: score of the k-th best entry after the last compaction
     uint32_t cnt[PQ_QG_MAX];   // wave-uniform list lengths
 #pragma unroll
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const uint32_t words = p.m >> 2, tail = p.m & 3;
 
-    for (uint32_t base = r0 + wave * 64; base < r1; base += 256) {
+    for (uint32_t base = r0 + wave * 64; base < r1; base += 64 * PQ_WAVES) {
         const uint32_t i = base + lane;
         bool live = i < r1;
         if (live && p.valid) live = bit_set(p.valid, i);
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
             const bool pass = live && (score > tau[g]);
             const uint64_t pm = __builtin_amdgcn_ballot_w64(pass);
             if (pm == 0) continue;
-            const uint32_t li = (g0 + g) * lists_per_q + split * 4 + wave;
+            const uint32_t li = (g0 + g) * lists_per_q + split * PQ_WAVES + wave;
             uint2* list = p.lists + (uint64_t)li * p.cap;
             if (pass) list[cnt[g] + __builtin_popcountll(pm & lt_mask)] = make_uint2(__float_as_uint(score), i);
             cnt[g] += __builtin_popcountll(pm);
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
 #pragma unroll
     for (int g = 0; g < PQ_QG_MAX; ++g) {
         if ((uint32_t)g >= p.qg || g0 + g >= p.q) continue;
-        const uint32_t li = (g0 + g) * lists_per_q + split * 4 + wave;
+        const uint32_t li = (g0 + g) * lists_per_q + split * PQ_WAVES + wave;
         if (cnt[g] > p.k) {
             wave_compact_list(p.lists + (uint64_t)li * p.cap, cnt[g], p.k, lane);
             cnt[g] = p.k;
@@ -126,7 +126,7 @@ hipError_t launch_pq_scan(const PqScanParams& p, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute((const void*)pq_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const dim3 grid(p.n_splits, (p.q + p.qg - 1) / p.qg);
-    hipLaunchKernelGGL(pq_scan_kernel, grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(pq_scan_kernel, grid, dim3(64 * PQ_WAVES), lds, stream, p);
     return hipGetLastError();
 }
 

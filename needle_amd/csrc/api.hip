@@ -167,7 +167,7 @@ void nh::index_free(needle_hip_index* ix) {
     for (DevBuf* b : {&ix->w_qraw, &ix->w_qop, &ix->w_qn2, &ix->w_lists, &ix->w_lcnt, &ix->w_cand, &ix->w_candn,
                       &ix->w_tau, &ix->w_flagged, &ix->w_flagcnt, &ix->w_filter, &ix->w_premax, &ix->w_tau0, &ix->x_keys, &ix->x_u32,
                       &ix->x_u64, &ix->x_sel, &ix->x_mask, &ix->v_probe_ids, &ix->v_probe_d, &ix->v_probe_n, &ix->v_probe32,
-                      &ix->v_items, &ix->v_itemq, &ix->r_idx, &ix->r_q, &ix->r_ids, &ix->r_dists, &ix->r_cnt})
+                      &ix->v_items, &ix->v_itemq, &ix->w_qerr, &ix->r_idx, &ix->r_q, &ix->r_ids, &ix->r_dists, &ix->r_cnt})
         b->release();
     delete ix;
 }
@@ -225,7 +225,7 @@ needle_hip_status nh::finish_operands(needle_hip_index* ix, bool validate) {
     if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, 2 * sizeof(uint32_t), c->stream);
     if (e == hipSuccess)
         e = launch_row_prep(ix->d_raw, rows, ix->dim, ix->dpad_f32, normalize, ix->op_f32_alias ? nullptr : ix->d_op_f32,
-                            nullptr, ix->d_cinit, ix->d_norms, nullptr, d_flag, c->stream);
+                            nullptr, ix->d_cinit, ix->d_norms, nullptr, d_flag, nullptr, nullptr, c->stream);
     uint32_t bits = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&bits, d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -353,7 +353,7 @@ struct SplitPlan { uint32_t n_splits, tiles_per_split, xcd_map; };
 static SplitPlan plan_splits(uint32_t q_tiles, uint32_t n_tiles, uint32_t slots, uint32_t max_splits) {
     SplitPlan best{1, n_tiles, 0};
     double best_score = -1.0;
-    const uint32_t s_max = std::min<uint32_t>(n_tiles, std::min<uint32_t>(64, max_splits));
+    const uint32_t s_max = std::min<uint32_t>(n_tiles, std::min<uint32_t>(256, max_splits));  // few query blocks: more slices
     for (uint32_t s = 1; s <= s_max; ++s) {
         const uint32_t tps = (n_tiles + s - 1) / s;
         const uint32_t s_eff = (n_tiles + tps - 1) / tps;
@@ -362,7 +362,7 @@ static SplitPlan plan_splits(uint32_t q_tiles, uint32_t n_tiles, uint32_t slots,
         const uint64_t rounds = (blocks + slots - 1) / slots;
         double score = (double)blocks / (double)(rounds * slots);
         if (tps < 8 && s > 1) score -= 0.05 * (8 - tps);  // list warm-up dominates tiny slices
-        score -= 0.001 * s;
+        score -= 0.0003 * s;
         const bool xcd = (s_eff % 8 == 0);
         if (xcd) score += 0.03;
         if (score > best_score) { best_score = score; best = SplitPlan{s_eff, tps, xcd ? 1u : 0u}; }
@@ -435,13 +435,23 @@ static needle_hip_status ensure_bf16_copy(needle_hip_index* ix) {
     ix->dpad_bf16 = flat_scan_bf16_dpad(ix->dim);
     const size_t bytes = (size_t)ix->n_pad * ix->dpad_bf16 * sizeof(uint16_t);
     uint16_t* d = nullptr;
+    uint32_t* d_bits = nullptr;
     HIP_TRY(hipMalloc((void**)&d, bytes));
-    hipError_t e = hipMemsetAsync(d, 0, bytes, c->stream);
-    if (e == hipSuccess)
+    hipError_t e = hipMalloc((void**)&d_bits, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(d_bits, 0, sizeof(uint32_t), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d, 0, bytes, c->stream);
+    const bool sq8 = ix->kind == KIND_SQ8;
+    if (e == hipSuccess && sq8)  // codes are exact in bf16; ix->bf16_err already holds max |code vector|
+        e = launch_sq8_codes_bf16(ix->d_codes, ix->n, ix->dim, ix->dpad_f32, ix->dpad_bf16, d, c->stream);
+    else if (e == hipSuccess)
         e = launch_row_prep(ix->d_raw, ix->n, ix->dim, ix->dpad_bf16, ix->metric == NEEDLE_METRIC_COSINE, nullptr, d,
-                            nullptr, nullptr, nullptr, nullptr, c->stream);
+                            nullptr, nullptr, nullptr, nullptr, nullptr, d_bits, c->stream);
+    uint32_t bits = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&bits, d_bits, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (d_bits) (void)hipFree(d_bits);
     if (e != hipSuccess) { (void)hipFree(d); HIP_TRY(e); }
+    if (!sq8) memcpy(&ix->bf16_err, &bits, sizeof(float));
     ix->d_op_bf16 = d;
     return NEEDLE_HIP_OK;
 }
@@ -454,7 +464,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     const uint32_t n = (uint32_t)ix->n;
     const bool sq8 = ix->kind == KIND_SQ8;
     // bf16 is a hint: code matrices and dimensions beyond the register-resident query block use fp32
-    if (precision == NEEDLE_PRECISION_BF16 && (sq8 || flat_scan_bf16_dpad(ix->dim) == 0)) precision = NEEDLE_PRECISION_FP32;
+    if (precision == NEEDLE_PRECISION_BF16 && flat_scan_bf16_dpad(ix->dim) == 0) precision = NEEDLE_PRECISION_FP32;
     if (precision == NEEDLE_PRECISION_BF16 && choose_kprime(std::min(k, n), precision) > KPRIME_MAX)
         precision = NEEDLE_PRECISION_FP32;
     const uint32_t kprime = choose_kprime(std::min(k, n), precision);
@@ -481,7 +491,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     SplitPlan plan = plan_splits(q_tiles, n_tiles, (uint32_t)c->n_cu * (uint32_t)flat_scan_blocks_per_cu(precision), max_splits);
     if (const char* ds = getenv("NEEDLE_HIP_DEBUG_SPLITS")) {  // development override, applied before any sizing
         const uint32_t s = (uint32_t)atoi(ds);
-        if (s >= 1 && s <= n_tiles && s <= 64 && s <= max_splits) {
+        if (s >= 1 && s <= n_tiles && s <= 256 && s <= max_splits) {
             plan.tiles_per_split = (n_tiles + s - 1) / s;
             plan.n_splits = (n_tiles + plan.tiles_per_split - 1) / plan.tiles_per_split;
             plan.xcd_map = (plan.n_splits % 8 == 0) ? 1u : 0u;
@@ -491,7 +501,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     const uint32_t n_lists = plan.n_splits * lists_per_split;  // per query
 
     HIP_TRY(ix->w_qop.ensure((size_t)q_pad * dpad * elt));
-    HIP_TRY(ix->w_qn2.ensure((size_t)q_pad * sizeof(double)));
+    HIP_TRY(ix->w_qn2.ensure((size_t)q_pad * 2 * sizeof(double)));  // second half: SQ8 |q / scale|^2
     HIP_TRY(ix->w_lists.ensure((size_t)q_pad * n_lists * cap * sizeof(uint2)));
     HIP_TRY(ix->w_lcnt.ensure((size_t)q_pad * n_lists * sizeof(uint32_t)));
     HIP_TRY(ix->w_cand.ensure((size_t)q * kprime * sizeof(uint32_t)));
@@ -499,22 +509,24 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     HIP_TRY(ix->w_tau.ensure((size_t)q * sizeof(float)));
     HIP_TRY(ix->w_flagged.ensure((size_t)q * sizeof(uint32_t)));
     HIP_TRY(ix->w_flagcnt.ensure(sizeof(uint32_t)));
+    if (bf16) HIP_TRY(ix->w_qerr.ensure((size_t)q_pad * sizeof(float)));
 
     HIP_TRY(hipMemsetAsync(ix->w_qop.p, 0, (size_t)q_pad * dpad * elt, c->stream));
     HIP_TRY(hipMemsetAsync(ix->w_flagcnt.p, 0, sizeof(uint32_t), c->stream));
     const bool normalize = ix->metric == NEEDLE_METRIC_COSINE;
     if (sq8)
-        HIP_TRY(launch_sq8_query_prep(d_queries, q, ix->dim, dpad, ix->d_sq_min, ix->d_sq_scale, ix->w_qop.as<float>(),
-                                      ix->w_qn2.as<double>(), c->stream));
+        HIP_TRY(launch_sq8_query_prep(d_queries, q, ix->dim, dpad, ix->d_sq_min, ix->d_sq_scale,
+                                      bf16 ? nullptr : ix->w_qop.as<float>(), bf16 ? ix->w_qop.as<uint16_t>() : nullptr,
+                                      ix->w_qn2.as<double>(), ix->w_qn2.as<double>() + q_pad, c->stream));
     else
         HIP_TRY(launch_row_prep(d_queries, q, ix->dim, dpad, normalize,
                                 precision == NEEDLE_PRECISION_BF16 ? nullptr : ix->w_qop.as<float>(),
                                 precision == NEEDLE_PRECISION_BF16 ? ix->w_qop.as<uint16_t>() : nullptr, nullptr, nullptr,
-                                ix->w_qn2.as<double>(), nullptr, c->stream));
+                                ix->w_qn2.as<double>(), nullptr, bf16 ? ix->w_qerr.as<float>() : nullptr, nullptr, c->stream));
 
     ScanParams sp{};
     sp.base_op = precision == NEEDLE_PRECISION_BF16 ? (const void*)ix->d_op_bf16 : (const void*)ix->d_op_f32;
-    if (sq8) { sp.base_op = ix->d_codes; sp.base_is_u8 = 1; }
+    if (sq8 && !bf16) { sp.base_op = ix->d_codes; sp.base_is_u8 = 1; }
     sp.query_op = ix->w_qop.p;
     sp.cinit = ix->d_cinit;
     sp.valid = ix->d_valid;
@@ -541,13 +553,22 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     if (const char* e = getenv("NEEDLE_HIP_DEBUG_PRE")) pre_tiles = std::min<uint32_t>((uint32_t)atoi(e), plan.tiles_per_split);
     if (const char* e = getenv("NEEDLE_HIP_DEBUG_KSEED")) sp.kseed = std::min<uint32_t>(std::max<uint32_t>((uint32_t)atoi(e), std::min(k, n)), kprime);
     const bool seeded = pre_tiles >= 1 && !(sp.debug & 2u);
+    TauBand band{};
+    band.qn2 = ix->w_qn2.as<double>();
+    band.qs2 = (sq8 && bf16) ? ix->w_qn2.as<double>() + q_pad : nullptr;
+    band.qerr = (bf16 && !sq8) ? ix->w_qerr.as<float>() : nullptr;
+    band.berr = ix->bf16_err;
+    band.bmax = ix->max_norm;
+    band.mnorm = ix->sq_min_norm * (1.0 + 1e-6);
+    band.dim = ix->dim; band.metric = ix->metric; band.precision = precision; band.sq8 = sq8 ? 1 : 0;
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (seeded) {
         HIP_TRY(ix->w_premax.ensure((size_t)q_pad * 8 * plan.n_splits * sizeof(float)));
         HIP_TRY(ix->w_tau0.ensure((size_t)q_pad * sizeof(float)));
         sp.pre_max = ix->w_premax.as<float>();
         sp.pre_tiles = pre_tiles;
-        HIP_TRY(launch_flat_prepass(precision, sp, ix->w_tau0.as<float>(), c->stream));
+        sp.pre_stride = std::max<uint32_t>(1, plan.tiles_per_split / pre_tiles);
+        HIP_TRY(launch_flat_prepass(precision, sp, ix->w_tau0.as<float>(), band, c->stream));
         sp.tau0 = ix->w_tau0.as<float>();
     }
     sp.tile_off = 0;
@@ -563,7 +584,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     }
     for (int r = 0; r < 3 && stages[r] > 0; ++r) {
         if (r > 0) {
-            HIP_TRY(launch_tau_refresh(sp, n_lists, ix->w_tau0.as<float>(), c->stream));
+            HIP_TRY(launch_tau_refresh(sp, n_lists, ix->w_tau0.as<float>(), band, c->stream));
             sp.resume = 1;
         }
         sp.tile_len = stages[r];
@@ -591,8 +612,12 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
         HIP_TRY(hipStreamSynchronize(c->stream));
         uint64_t tot = 0; uint32_t mx = 0;
         for (size_t i = 0; i < (size_t)q * n_lists; ++i) { tot += lc[i]; mx = std::max(mx, lc[i]); }
-        fprintf(stderr, "[needle_hip] listed candidates: %.1f per query, longest list %u, lists per query %u, kprime %u, kseed %u, pre_tiles %u\n",
-                (double)tot / std::max<uint32_t>(q, 1), mx, n_lists, kprime, sp.kseed, seeded ? pre_tiles : 0);
+        float dbg_ms = -1.0f;
+        if (c->profiling) (void)hipEventElapsedTime(&dbg_ms, c->ev[0], c->ev[1]);
+        fprintf(stderr, "[needle_hip] q %u: listed candidates %.1f per query, longest list %u, lists per query %u, kprime %u, kseed %u, "
+                "pre_tiles %u, slices %u x %u tiles, query blocks %u, first pass %s %.3f ms\n",
+                q, (double)tot / std::max<uint32_t>(q, 1), mx, n_lists, kprime, sp.kseed, seeded ? pre_tiles : 0, plan.n_splits,
+                plan.tiles_per_split, q_tiles, bf16 ? "bf16" : "fp32", dbg_ms);
     }
 
     PostParams pp{};
@@ -613,9 +638,12 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     pp.q = q; pp.n = n; pp.dim = ix->dim; pp.k = k; pp.kprime = kprime; pp.cap = cap; pp.n_splits = n_lists;
     pp.metric = ix->metric; pp.arith = ix->arith; pp.precision = precision;
     pp.max_norm = ix->max_norm;
+    pp.qerr = (bf16 && !sq8) ? ix->w_qerr.as<float>() : nullptr;
+    pp.berr = ix->bf16_err;
     if (sq8) {
         pp.sq_codes = ix->d_codes; pp.sq_min = ix->d_sq_min; pp.sq_scale = ix->d_sq_scale; pp.sq_stride = ix->dpad_f32;
         pp.aux_norm = (float)(ix->sq_min_norm * (1.0 + 1e-6));
+        if (bf16) pp.qaux = ix->w_qn2.as<double>() + q_pad;
     }
     HIP_TRY(launch_merge_select(pp, c->stream));
     HIP_TRY(launch_rescore_finalize(pp, c->stream));
@@ -633,9 +661,10 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     }
     if (n_flagged > 0) {
         if (n_flagged > q) n_flagged = q;
-        if (bf16) {
+        if (bf16 && n_flagged > 16) {
             // The bf16 scores could not separate these queries' k-th hit from the rows left out: give them
             // the fp32 first pass (whose own leftovers go to the exact scan) and put the answers in place.
+            // (A handful of queries is cheaper on the exact scan, which streams the base once per 4 of them.)
             HIP_TRY(ix->r_idx.ensure((size_t)n_flagged * sizeof(uint32_t)));
             HIP_TRY(ix->r_q.ensure((size_t)n_flagged * ix->dim * sizeof(float)));
             HIP_TRY(ix->r_ids.ensure((size_t)n_flagged * k * sizeof(uint64_t)));

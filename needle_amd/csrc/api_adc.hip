@@ -52,13 +52,13 @@ needle_hip_status nh::pq_search_batch_device(needle_hip_index* ix, const float* 
     const uint32_t qg = pq_scan_queries_per_block(ix->pq_m);
     const uint32_t groups = (q + qg - 1) / qg;
     // slices of the code matrix: enough workgroups to fill the chip, slices of >= 4096 rows,
-    // and 4 * S lists of k entries per query must fit the merge kernel's LDS
+    // and PQ_WAVES * S lists of k entries per query must fit the merge kernel's LDS
     uint32_t S = std::max<uint32_t>(1, (4u * (uint32_t)c->n_cu + groups - 1) / groups);
-    S = std::min<uint32_t>(S, std::max<uint32_t>(1, n / 4096));
-    S = std::min<uint32_t>(S, std::max<uint32_t>(1, 60000u / (4u * k * (uint32_t)sizeof(uint64_t))));
+    S = std::min<uint32_t>(S, std::max<uint32_t>(1, n / (1024u * PQ_WAVES)));
+    S = std::min<uint32_t>(S, std::max<uint32_t>(1, 60000u / ((uint32_t)PQ_WAVES * k * (uint32_t)sizeof(uint64_t))));
     const uint32_t rows_per_split = (n + S - 1) / S;
     S = (n + rows_per_split - 1) / rows_per_split;
-    const uint32_t lists_per_q = 4 * S, cap = 2 * k + 64;
+    const uint32_t lists_per_q = PQ_WAVES * S, cap = 2 * k + 64;
 
     HIP_TRY(ix->w_lists.ensure((size_t)q * lists_per_q * cap * sizeof(uint2)));
     HIP_TRY(ix->w_lcnt.ensure((size_t)q * lists_per_q * sizeof(uint32_t)));
@@ -149,15 +149,16 @@ extern "C" needle_hip_status needle_hip_sq8_build(needle_hip_ctx* c, const uint8
             e = hipMemcpy2DAsync(ix->d_codes, ix->dpad_f32, codes, dim, dim, n, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMalloc((void**)&ix->d_cinit, sizeof(float) * ix->n_pad);
         if (e == hipSuccess) e = hipMemsetAsync(ix->d_cinit, 0, sizeof(float) * ix->n_pad, c->stream);
-        if (e == hipSuccess) e = hipMalloc((void**)&d_bits, sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemsetAsync(d_bits, 0, sizeof(uint32_t), c->stream);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_bits, 2 * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(d_bits, 0, 2 * sizeof(uint32_t), c->stream);
         if (e == hipSuccess)
             e = launch_sq8_row_prep(ix->d_codes, n, dim, ix->dpad_f32, ix->d_sq_min, ix->d_sq_scale, ix->d_cinit, d_bits,
                                     c->stream);
-        uint32_t bits = 0;
-        if (e == hipSuccess) e = hipMemcpyAsync(&bits, d_bits, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+        uint32_t bits[2] = {0, 0};
+        if (e == hipSuccess) e = hipMemcpyAsync(bits, d_bits, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        memcpy(&ix->max_norm, &bits, sizeof(float));
+        memcpy(&ix->max_norm, &bits[0], sizeof(float));
+        memcpy(&ix->bf16_err, &bits[1], sizeof(float));  // max |code vector|: scales the bf16 query rounding error
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (d_bits) (void)hipFree(d_bits);

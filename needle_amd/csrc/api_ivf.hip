@@ -260,7 +260,7 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     HIP_TRY(hipMemsetAsync(ix->w_lcnt.p, 0, (size_t)q * np * sizeof(uint32_t), c->stream));
     HIP_TRY(hipMemsetAsync(ix->w_flagcnt.p, 0, sizeof(uint32_t), c->stream));
     HIP_TRY(launch_row_prep(d_queries, q, ix->dim, dpad, false, ix->w_qop.as<float>(), nullptr, nullptr, nullptr,
-                            ix->w_qn2.as<double>(), nullptr, c->stream));
+                            ix->w_qn2.as<double>(), nullptr, nullptr, nullptr, c->stream));
 
     ScanParams sp{};
     sp.base_op = ix->d_op_f32;

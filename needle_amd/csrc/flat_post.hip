@@ -95,13 +95,13 @@ hipError_t launch_merge_select(const PostParams& p, hipStream_t stream) {
 // the few extra roundings of normalisation, sqrt and divide.  A bf16 operand
 // pair adds 2^-8 relative per product.
 // ---------------------------------------------------------------------------
-__device__ inline bool bound_check(int metric, int precision, float tau, float dk, double qn2,
+__device__ inline bool bound_check(int metric, double lowp_abs, float tau, float dk, double qn2,
                                    double bmax, uint32_t dim) {
     if (tau == -INFINITY) return true;  // every live row was re-scored
     if (!(dk == dk) || !(tau == tau)) return false;
     const double u = 5.9604644775390625e-08;
     const double gam = 2.0 * ((double)dim + 16.0) * u;
-    const double lowp = (precision == NEEDLE_PRECISION_BF16) ? (1.01 / 256.0) : 0.0;
+    const double lowp = lowp_abs;  // absolute first-pass error from operand rounding (bf16_score_err)
     const double qn = sqrt(qn2);
     const double t = (double)tau, d = (double)dk;
     switch (metric) {
@@ -114,17 +114,17 @@ __device__ inline bool bound_check(int metric, int precision, float tau, float d
     case NEEDLE_METRIC_COSINE_NORMALIZED: {
         const double scale = qn * bmax;
         if (!(scale < 1e17)) return false;
-        return (1.0 - t - (lowp + 2.0 * gam) * scale) > d;
+        return (1.0 - t - lowp - 2.0 * gam * scale) > d;
     }
     case NEEDLE_METRIC_DOT_PRODUCT: {
         const double scale = qn * bmax;
         if (!(scale < 1e17)) return false;
-        return (-t - (lowp + 2.0 * gam) * scale) > d;
+        return (-t - lowp - 2.0 * gam * scale) > d;
     }
     case NEEDLE_METRIC_EUCLIDEAN: {
         // score = q.b - |b|^2/2  ->  d^2 = |q|^2 - 2*score
         if (!(qn < 1e17) || !(bmax < 1e17)) return false;
-        const double eps_s = (lowp + gam) * qn * bmax + gam * 0.5 * bmax * bmax;
+        const double eps_s = lowp + gam * qn * bmax + gam * 0.5 * bmax * bmax;
         const double d2 = qn2 - 2.0 * t - 2.0 * eps_s;
         if (!(d2 > 0.0)) return false;
         return sqrt(d2) * (1.0 - gam) > d;
@@ -137,7 +137,10 @@ __device__ inline bool bound_check(int metric, int precision, float tau, float d
 // squared distance is qconst - 2*score, qconst = sum_j (q_j^2 - 2 q_j min_j).  vmax = max |v|,
 // mnorm = |min_vals|.  Both the first-pass score and the reference's own value (decode, subtract,
 // square, sequential sum) err by at most gam * (|q| + |v| + |min|)^2-sized terms.
-__device__ inline bool bound_check_sq8(float tau, float dk, double qconst, double vmax, double mnorm, uint32_t dim) {
+// lowp_e: absolute error the operand rounding adds to a first-pass score (bf16 query operand against exact
+// codes: 2^-9 |q/scale| |c| with |c| <= 255 sqrt(dim)); 0 for f32 operands.
+__device__ inline bool bound_check_sq8(float tau, float dk, double qconst, double vmax, double mnorm, uint32_t dim,
+                                       double lowp_e) {
     if (tau == -INFINITY) return true;
     if (!(dk == dk) || !(tau == tau)) return false;
     const double u = 5.9604644775390625e-08;
@@ -145,7 +148,7 @@ __device__ inline bool bound_check_sq8(float tau, float dk, double qconst, doubl
     // |q| <= sqrt(|qconst| + 2|q||min|): bound |q| through qconst = |q|^2 - 2 q.min  ->  |q| <= |min| + sqrt(|min|^2 + |qconst|)
     const double qn = mnorm + sqrt(mnorm * mnorm + fabs(qconst));
     if (!(qn < 1e17) || !(vmax < 1e17)) return false;
-    const double eps_s = gam * (qn * (vmax + mnorm) + 0.5 * vmax * vmax);
+    const double eps_s = gam * (qn * (vmax + mnorm) + 0.5 * vmax * vmax) + lowp_e;
     const double lb2 = qconst - 2.0 * (double)tau - 2.0 * eps_s;
     if (!(lb2 > 0.0)) return false;
     const double lb = sqrt(lb2);
@@ -165,12 +168,19 @@ __device__ inline bool bound_check_sq8(float tau, float dk, double qconst, doubl
 // the arithmetic is the scalar sequence of nh_exact.h continued across the blocks.
 struct RefAcc { float a, b, c; };  // running sums: a = dot | squared distance, b = |q|^2, c = |row|^2
 
-enum RefKind { RK_RS_COS, RK_RS_DOT, RK_RS_L2, RK_C4_COS, RK_C4_DOT, RK_C4_L2 };
+enum RefKind { RK_RS_COS, RK_RS_DOT, RK_RS_L2, RK_C4_COS, RK_C4_DOT, RK_C4_L2, RK_L1, RK_HAMMING, RK_CHEB };
 
 __device__ inline int ref_kind(int metric, int arith) {
     if (arith == NEEDLE_ARITH_ACCEL_CHUNK4)
         return metric == NEEDLE_METRIC_COSINE ? RK_C4_COS : (metric == NEEDLE_METRIC_EUCLIDEAN ? RK_C4_L2 : RK_C4_DOT);
-    return metric == NEEDLE_METRIC_COSINE ? RK_RS_COS : (metric == NEEDLE_METRIC_EUCLIDEAN ? RK_RS_L2 : RK_RS_DOT);
+    switch (metric) {
+    case NEEDLE_METRIC_COSINE: return RK_RS_COS;
+    case NEEDLE_METRIC_EUCLIDEAN: return RK_RS_L2;
+    case NEEDLE_METRIC_MANHATTAN: return RK_L1;
+    case NEEDLE_METRIC_HAMMING: return RK_HAMMING;
+    case NEEDLE_METRIC_CHEBYSHEV: return RK_CHEB;
+    default: return RK_RS_DOT;  // CosineNormalized, DotProduct
+    }
 }
 
 // dims [i0, i1) of the vectors, staged at qs[0 .. i1-i0) and bs[0 .. i1-i0); i0 is a multiple of 4
@@ -187,6 +197,15 @@ __device__ inline void ref_accumulate(RefAcc& s, const float* qs, const float* b
         for (uint32_t i = 0; i < i1 - i0; ++i) { const float pxy = qs[i] * bs[i]; s.a = s.a + pxy; }
     } else if (KIND == RK_RS_L2) {  // distance.rs:249-257
         for (uint32_t i = 0; i < i1 - i0; ++i) { const float d = qs[i] - bs[i]; const float pd = d * d; s.a = s.a + pd; }
+    } else if (KIND == RK_L1) {  // distance.rs:360-362
+        for (uint32_t i = 0; i < i1 - i0; ++i) s.a = s.a + fabsf(qs[i] - bs[i]);
+    } else if (KIND == RK_HAMMING) {  // distance.rs:387-395 (a count: exact in f32 below 2^24 dimensions)
+        for (uint32_t i = 0; i < i1 - i0; ++i) s.a = s.a + (((qs[i] != 0.0f) != (bs[i] != 0.0f)) ? 1.0f : 0.0f);
+    } else if (KIND == RK_CHEB) {  // distance.rs:415-423: fold(0.0, f32::max), max drops NaN
+        for (uint32_t i = 0; i < i1 - i0; ++i) {
+            const float d = fabsf(qs[i] - bs[i]);
+            s.a = (d != d) ? s.a : ((s.a != s.a) ? d : (d > s.a ? d : s.a));
+        }
     } else {  // gpu/common.rs:515-581: groups of four, then the remainder one by one
         const uint32_t grouped = (dim / 4) * 4;
         uint32_t i = i0;
@@ -315,8 +334,12 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams
         }
         if (rank + 1 == k_eff) {
             const bool ok = p.sq_codes
-                                ? bound_check_sq8(p.tau_star[q], d, p.qnorm2[q], (double)p.max_norm, (double)p.aux_norm, p.dim)
-                                : bound_check(p.metric, p.precision, p.tau_star[q], d, p.qnorm2[q], (double)p.max_norm, p.dim);
+                                ? bound_check_sq8(p.tau_star[q], d, p.qnorm2[q], (double)p.max_norm, (double)p.aux_norm, p.dim,
+                                                  p.qaux ? 1.000001 * sqrt(p.qaux[q]) * p.berr : 0.0)
+                                : bound_check(p.metric,
+                                              bf16_score_err(p.metric, sqrt(p.qnorm2[q]), (double)p.max_norm,
+                                                             p.qerr ? (double)p.qerr[q] : -1.0, p.berr),
+                                              p.tau_star[q], d, p.qnorm2[q], (double)p.max_norm, p.dim);
             if (!ok) p.flagged[atomicAdd(p.flag_count, 1u)] = q;
         }
     }
@@ -382,30 +405,101 @@ hipError_t launch_emit_sorted(const PostParams& p, hipStream_t stream) {
 // ones otherwise; the k-th smallest key is found by an 8-bit-per-pass radix
 // descent over histograms, the keys <= it are gathered and ranked.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void exact_keys_kernel(ExactParams p) {
-    const uint32_t f = blockIdx.y;
-    const uint32_t q = p.qsel ? p.qsel[f] : f;
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    bool live = i < p.n;
+// One workgroup = 256 rows x up to EX_SLOTS slots (queries).  The rows are staged through LDS a block of
+// dimensions at a time with coalesced reads (thread t then walks row t of the staged block), so the base is
+// read once per EX_SLOTS slots at streaming speed; the arithmetic per (row, slot) is the scalar sequence of
+// nh_exact.h continued across the blocks.
+constexpr int EX_ROWS = 256, EX_DC = 32, EX_LD = EX_DC + 1, EX_SLOTS = 4;
+
+template <int KIND>
+__device__ inline void exact_accumulate_slots(RefAcc (&acc)[EX_SLOTS], const float (*qs)[EX_DC], const float* bs, uint32_t i0,
+                                              uint32_t i1, uint32_t dim, uint32_t slots) {
+#pragma unroll
+    for (int s = 0; s < EX_SLOTS; ++s)
+        if ((uint32_t)s < slots) ref_accumulate<KIND>(acc[s], qs[s], bs, i0, i1, dim);
+}
+
+__global__ __launch_bounds__(EX_ROWS) void exact_keys_kernel(ExactParams p) {
+    __shared__ float rows[EX_ROWS * EX_LD];
+    __shared__ float qs[EX_SLOTS][EX_DC];
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t f0 = blockIdx.y * EX_SLOTS;
+    const uint32_t slots = min((uint32_t)EX_SLOTS, p.f - f0);
+    const uint32_t row0 = blockIdx.x * EX_ROWS;
+    const uint32_t i = row0 + t;
+    uint32_t qidx[EX_SLOTS];
+    bool live[EX_SLOTS];
     uint32_t id = i;
-    if (live && p.pos2id) { id = p.pos2id[i]; live = id != 0xffffffffu; }
-    if (live && p.pos_filter) live = bit_set(p.pos_filter + (uint64_t)f * p.pos_filter_words, i);
-    if (live && p.valid) live = bit_set(p.valid, id);
-    if (live && p.filter) live = bit_set(p.filter, id);
-    uint64_t key = ~0ull;
-    if (live) {
-        float d;
-        if (p.sq_codes)
-            d = exact_sq8(p.query_raw + (uint64_t)q * p.dim, p.sq_codes + (uint64_t)i * p.sq_stride, p.sq_min, p.sq_scale,
-                          p.dim);
-        else
-            d = exact_distance(p.metric, p.arith, p.query_raw + (uint64_t)q * p.dim, p.base_raw + (uint64_t)i * p.dim,
-                               p.dim);
-        key = hit_key(canon_distance(d), id);
+    bool row_ok = i < p.n;
+    if (row_ok && p.pos2id) { id = p.pos2id[i]; row_ok = id != 0xffffffffu; }
+    if (row_ok && p.valid) row_ok = bit_set(p.valid, id);
+    if (row_ok && p.filter) row_ok = bit_set(p.filter, id);
+#pragma unroll
+    for (int s = 0; s < EX_SLOTS; ++s) {
+        const uint32_t f = f0 + min((uint32_t)s, slots - 1);
+        qidx[s] = p.qsel ? p.qsel[f] : f;
+        live[s] = row_ok && (uint32_t)s < slots;
+        if (live[s] && p.pos_filter) live[s] = bit_set(p.pos_filter + (uint64_t)f * p.pos_filter_words, i);
     }
-    if (i < p.n) p.keys[(uint64_t)f * p.n + i] = key;
-    const uint64_t m = __builtin_amdgcn_ballot_w64(live);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&p.live[f], (uint32_t)__builtin_popcountll(m));
+    const bool sq8 = p.sq_codes != nullptr;
+    const int kind = sq8 ? (int)RK_RS_L2 : ref_kind(p.metric, p.arith);
+    RefAcc acc[EX_SLOTS];
+    // Rust's f32 Sum folds from -0.0; the accelerator's sums, the SQ8 sum, the Hamming count and the
+    // Chebyshev fold start from +0.0
+    const float zero = (sq8 || p.arith == NEEDLE_ARITH_ACCEL_CHUNK4 || kind == RK_HAMMING || kind == RK_CHEB) ? 0.0f : -0.0f;
+#pragma unroll
+    for (int s = 0; s < EX_SLOTS; ++s) { acc[s].a = zero; acc[s].b = zero; acc[s].c = zero; }
+
+    const uint32_t rows_here = min((uint32_t)EX_ROWS, p.n > row0 ? p.n - row0 : 0u);
+    for (uint32_t c0 = 0; c0 < p.dim; c0 += EX_DC) {
+        const uint32_t len = min((uint32_t)EX_DC, p.dim - c0);
+        __syncthreads();
+        if (t < EX_SLOTS * EX_DC) {
+            const uint32_t s = t / EX_DC, j = t % EX_DC;
+            qs[s][j] = j < len ? p.query_raw[(uint64_t)qidx[s] * p.dim + c0 + j] : 0.0f;
+        }
+        // wave w stages rows w*64 .. w*64+63, two rows per step (32 lanes each)
+        for (uint32_t r = wave * 64 + (lane >> 5); r < wave * 64 + 64; r += 2) {
+            const uint32_t j = lane & 31;
+            float v = 0.0f;
+            if (r < rows_here && j < len) {
+                if (sq8) {  // decoded exactly as ScalarQuantizer::dequantize / asymmetric_distance do
+                    const float cv = (float)p.sq_codes[(uint64_t)(row0 + r) * p.sq_stride + c0 + j];
+                    v = (cv / p.sq_scale[c0 + j]) + p.sq_min[c0 + j];
+                } else {
+                    v = p.base_raw[(uint64_t)(row0 + r) * p.dim + c0 + j];
+                }
+            }
+            rows[r * EX_LD + j] = v;
+        }
+        __syncthreads();
+        const float* bs = rows + t * EX_LD;
+        switch (kind) {
+        case RK_RS_COS: exact_accumulate_slots<RK_RS_COS>(acc, qs, bs, c0, c0 + len, p.dim, slots); break;
+        case RK_RS_DOT: exact_accumulate_slots<RK_RS_DOT>(acc, qs, bs, c0, c0 + len, p.dim, slots); break;
+        case RK_RS_L2: exact_accumulate_slots<RK_RS_L2>(acc, qs, bs, c0, c0 + len, p.dim, slots); break;
+        case RK_C4_COS: exact_accumulate_slots<RK_C4_COS>(acc, qs, bs, c0, c0 + len, p.dim, slots); break;
+        case RK_C4_DOT: exact_accumulate_slots<RK_C4_DOT>(acc, qs, bs, c0, c0 + len, p.dim, slots); break;
+        case RK_C4_L2: exact_accumulate_slots<RK_C4_L2>(acc, qs, bs, c0, c0 + len, p.dim, slots); break;
+        case RK_L1: exact_accumulate_slots<RK_L1>(acc, qs, bs, c0, c0 + len, p.dim, slots); break;
+        case RK_HAMMING: exact_accumulate_slots<RK_HAMMING>(acc, qs, bs, c0, c0 + len, p.dim, slots); break;
+        default: exact_accumulate_slots<RK_CHEB>(acc, qs, bs, c0, c0 + len, p.dim, slots); break;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < EX_SLOTS; ++s) {
+        if ((uint32_t)s >= slots) continue;  // block-uniform
+        const uint32_t f = f0 + s;
+        uint64_t key = ~0ull;
+        if (live[s]) {
+            float v = ref_finish(kind, acc[s]);
+            if (kind == RK_RS_DOT || kind == RK_C4_DOT) v = p.metric == NEEDLE_METRIC_COSINE_NORMALIZED ? 1.0f - v : -v;
+            key = hit_key(canon_distance(v), id);
+        }
+        if (i < p.n) p.keys[(uint64_t)f * p.n + i] = key;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(live[s]);
+        if (lane == 0 && m) atomicAdd(&p.live[f], (uint32_t)__builtin_popcountll(m));
+    }
 }
 
 __global__ void exact_init_kernel(ExactParams p) {
@@ -550,7 +644,7 @@ hipError_t launch_exact_scan(const ExactParams& p, hipStream_t stream) {
     if ((e = hipMemsetAsync(p.hist, 0, sizeof(uint32_t) * 256 * p.f, stream)) != hipSuccess) return e;
     const uint32_t nb = (p.n + 255) / 256;
     const uint32_t fb = (p.f + 63) / 64;
-    if (nb) hipLaunchKernelGGL(exact_keys_kernel, dim3(nb, p.f), dim3(256), 0, stream, p);
+    if (nb) hipLaunchKernelGGL(exact_keys_kernel, dim3(nb, (p.f + EX_SLOTS - 1) / EX_SLOTS), dim3(EX_ROWS), 0, stream, p);
     hipLaunchKernelGGL(exact_init_kernel, dim3(fb), dim3(64), 0, stream, p);
     const uint32_t hb = nb < 1024 ? (nb ? nb : 1) : 1024;
     for (int shift = 56; shift >= 0; shift -= 8) {

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
     const uint32_t jq = wave * 32 + l31;  // this lane's query slot within the block
 
     uint32_t t0, t1, split = 0, q0 = 0;
+    uint32_t tile_first = 0, tile_mul = 1;  // FLAT / PRE: position jj of the block's run is tile tile_first + jj * tile_mul
     uint32_t list_idx = 0;       // candidate list of this lane's query
     uint32_t my_query = 0;       // row of query_op this lane's column multiplies
     bool q_live = true;          // false: padding slot of an IVF item
@@ -111,9 +112,13 @@ __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
             q_tile = blockIdx.x % p.q_tiles;
         }
         q0 = q_tile * TILE_QUERIES;
-        t0 = split * p.tiles_per_split;
-        t1 = min(t0 + p.tiles_per_split, p.n_tiles);
-        if (MODE == MODE_PRE) t1 = min(t1, t0 + p.pre_tiles);
+        // slice `split` owns tiles split, split + n_splits, ...; the pre-pass samples every pre_stride-th of them
+        const uint32_t own = split < p.n_tiles ? (p.n_tiles - split + p.n_splits - 1) / p.n_splits : 0u;
+        const uint32_t jstep = MODE == MODE_PRE ? max(p.pre_stride, 1u) : 1u;
+        t0 = 0;
+        t1 = MODE == MODE_PRE ? min(p.pre_tiles, (own + jstep - 1) / jstep) : own;
+        tile_first = split;
+        tile_mul = jstep * p.n_splits;
         my_query = q0 + jq;
         list_idx = my_query * p.n_splits + split;
 #pragma unroll
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
 
     f32x4 ra[4], rb[4];
     auto load_chunk = [&](uint32_t c) {
-        const uint32_t tile = t0 + c / KC, kc = c % KC;
+        const uint32_t tile = tile_first + (t0 + c / KC) * tile_mul, kc = c % KC;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t idx = tid + i * 256, r = idx >> 3, c4 = idx & 7;
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
     }
     __syncthreads();
     for (uint32_t c = 0; c < total; ++c) {
-        const uint32_t buf = c & 1, kc = c % KC, tile = t0 + c / KC;
+        const uint32_t buf = c & 1, kc = c % KC, tile = tile_first + (t0 + c / KC) * tile_mul;
         if (c + 1 < total) load_chunk(c + 1);  // in flight behind this chunk's MFMAs
         if (kc == 0) {
             if (p.cinit) {
@@ -241,11 +246,18 @@ __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
     if (h == 0 && q_live) p.list_counts[list_idx] = cnt;
 }
 
+__device__ inline double band_eps(const TauBand& band, uint32_t q) {
+    if (band.sq8) return score_eps_sq8(band.qn2[q], band.bmax, band.mnorm, band.dim, band.qs2 ? band.qs2[q] : -1.0, band.berr);
+    const double qn = sqrt(band.qn2[q]);
+    const double lowp = bf16_score_err(band.metric, qn, band.bmax, band.qerr ? (double)band.qerr[q] : -1.0, band.berr);
+    return score_eps(band.metric, lowp, qn, band.bmax, band.dim);
+}
+
 // One wave per query, between two launches that share candidate lists: with at least kseed candidates listed,
 // the kseed-th largest listed score is a threshold that kseed live rows reach; the next launch starts from it.
 __global__ __launch_bounds__(64) void tau_refresh_kernel(const uint2* __restrict__ lists, const uint32_t* __restrict__ counts,
                                                          uint32_t n_lists, uint32_t cap, uint32_t kprime, uint32_t kseed,
-                                                         float* __restrict__ tau) {
+                                                         float* __restrict__ tau, TauBand band) {
     constexpr uint32_t MAXE = 1024;  // more listed than this: keep the threshold (the lists are long anyway)
     __shared__ uint32_t ord[MAXE];
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
@@ -277,19 +289,25 @@ __global__ __launch_bounds__(64) void tau_refresh_kernel(const uint2* __restrict
         }
         if (cnt >= kseed) prefix = trial;
     }
-    if (lane == 0) tau[q] = fmaxf(tau[q], ord2f(prefix));
+    if (lane == 0) {
+        // Stay below the kseed-th listed score by a few times the score uncertainty: the rows inside that band
+        // are the ones the bound check needs to see listed before it can certify the k-th hit.
+        const double eps = band_eps(band, q);
+        const float t = (float)((double)ord2f(prefix) - 2.0 * eps);
+        if (t == t) tau[q] = fmaxf(tau[q], t);
+    }
 }
 
-hipError_t launch_tau_refresh(const ScanParams& p, uint32_t n_lists, float* d_tau, hipStream_t stream) {
+hipError_t launch_tau_refresh(const ScanParams& p, uint32_t n_lists, float* d_tau, const TauBand& band, hipStream_t stream) {
     if (p.n_queries == 0) return hipSuccess;
     hipLaunchKernelGGL(tau_refresh_kernel, dim3(p.n_queries), dim3(64), 0, stream, p.lists, p.list_counts, n_lists, p.cap,
-                       p.kprime, p.kseed, d_tau);
+                       p.kprime, p.kseed, d_tau, band);
     return hipGetLastError();
 }
 
 // One wave per query: tau0 = (kprime-th largest of the query's group maxima) - 2 ulps.
 __global__ __launch_bounds__(64) void tau0_kernel(const float* __restrict__ pre_max, uint32_t groups,
-                                                  uint32_t kprime, float* __restrict__ tau0) {
+                                                  uint32_t kprime, float* __restrict__ tau0, TauBand band, uint32_t n_queries) {
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
     const float* v = pre_max + (uint64_t)q * groups;
     uint32_t prefix = 0;
@@ -307,7 +325,14 @@ __global__ __launch_bounds__(64) void tau0_kernel(const float* __restrict__ pre_
     if (lane == 0) {
         float t = -INFINITY;
         // f2ord(-inf) = 0x007fffff; anything at or below it means "no threshold"
-        if (groups >= kprime && prefix > 0x00800001u) t = ord2f(prefix - 2);
+        if (groups >= kprime && prefix > 0x00800001u) {
+            t = ord2f(prefix - 2);
+            // as in the refresh between launches: leave the band of scores the bound check must see listed
+            if (q < n_queries) {
+                const float tb = (float)((double)t - 2.0 * band_eps(band, q));
+                if (tb == tb) t = fminf(t, tb);
+            }
+        }
         tau0[q] = t;
     }
 }
@@ -324,7 +349,7 @@ hipError_t launch_flat_scan(int precision, const ScanParams& p, hipStream_t stre
     return hipGetLastError();
 }
 
-hipError_t launch_flat_prepass(int precision, const ScanParams& p, float* d_tau0, hipStream_t stream) {
+hipError_t launch_flat_prepass(int precision, const ScanParams& p, float* d_tau0, const TauBand& band, hipStream_t stream) {
     const uint32_t grid = p.n_splits * p.q_tiles;
     if (grid == 0) return hipSuccess;
     if (precision == NEEDLE_PRECISION_FP32) {
@@ -335,7 +360,7 @@ hipError_t launch_flat_prepass(int precision, const ScanParams& p, float* d_tau0
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(tau0_kernel, dim3(p.q_tiles * flat_scan_queries_per_block(precision, p.dpad)), dim3(64), 0, stream,
-                       p.pre_max, 8 * p.n_splits, p.kseed, d_tau0);
+                       p.pre_max, 8 * p.n_splits, p.kseed, d_tau0, band, p.n_queries);
     return hipGetLastError();
 }
 

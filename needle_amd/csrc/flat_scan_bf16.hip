@@ -132,15 +132,18 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
         q_tile = blockIdx.x % p.q_tiles;
     }
     const uint32_t q0 = q_tile * QB + wave * (32 * NT);  // first query of this wave
-    uint32_t t0 = split * p.tiles_per_split;
-    uint32_t t1 = min(t0 + p.tiles_per_split, p.n_tiles);
+    // the block's run: tiles split + (jb + jj * jstep) * n_splits, jj = 0 .. cnt-1
+    const uint32_t own = split < p.n_tiles ? (p.n_tiles - split + p.n_splits - 1) / p.n_splits : 0u;  // tiles of this slice
+    uint32_t jb = 0, jstep = 1, cnt_tiles;
     if (MODE == MODE_PRE) {
-        t1 = min(t1, t0 + p.pre_tiles);
+        jstep = max(p.pre_stride, 1u);
+        cnt_tiles = min(p.pre_tiles, (own + jstep - 1) / jstep);
     } else {
-        t0 = min(t0 + p.tile_off, t1);
-        t1 = min(t0 + p.tile_len, t1);
+        jb = min(p.tile_off, own);
+        cnt_tiles = min(p.tile_len, own - jb);
     }
-
+    const uint32_t tile_mul = jstep * p.n_splits, tile_first = split + jb * p.n_splits;
+    const uint32_t t0 = 0, t1 = cnt_tiles;  // positions jj of the run
     float tau[NT];
     uint32_t cnt[NT], list_idx[NT];
     float gmax[NT][4];
@@ -189,7 +192,8 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
         }
         // fill slot `slot` with stage u (0 .. UT-1) of tile `tile` (tile clamped by the caller); piece i = 0..3, or
         // all four.  The accumulator seeds of a half tile travel with piece 3 of its first stage.
-        auto issue_piece = [&](uint32_t tile, int u, uint32_t slot, int i) {
+        auto issue_piece = [&](uint32_t jj, int u, uint32_t slot, int i) {
+            const uint32_t tile = tile_first + jj * tile_mul;
             const uint32_t half = (uint32_t)(u / STAGES), s2 = (uint32_t)(u % STAGES);
             const unsigned char* src = gA + (uint64_t)(tile * TILE_ROWS + half * BF_ROWS) * row_bytes + s2 * 256u;
             unsigned char* dst = smem + slot * BF_STAGE_BYTES + wave * 4096u;
@@ -232,7 +236,8 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
 
         f32x16 acc[2][NT];
         uint32_t slot = 0;  // slot of the stage being multiplied
-        for (uint32_t tile = t0; tile < t1; ++tile) {
+        for (uint32_t jj = t0; jj < t1; ++jj) {
+            const uint32_t tile = tile_first + jj * tile_mul;
             static_for<2>([&](auto half_c) {
                 constexpr int half = decltype(half_c)::value;
                 static_for<STAGES>([&](auto s_c) {
@@ -275,10 +280,10 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
                         }
                         if (BF_FILL_SPREAD) {
                             if (kk >= BF_FILL_KK && kk < BF_FILL_KK + 4)
-                                issue_piece(min(tile + (uint32_t)((u + BF_PD) / UT), t1 - 1), (u + BF_PD) % UT,
+                                issue_piece(min(jj + (uint32_t)((u + BF_PD) / UT), t1 - 1), (u + BF_PD) % UT,
                                             (slot + BF_PD) % BF_NBUF, kk - BF_FILL_KK);
                         } else if (kk == BF_FILL_KK) {
-                            issue_stage(min(tile + (uint32_t)((u + BF_PD) / UT), t1 - 1), (u + BF_PD) % UT,
+                            issue_stage(min(jj + (uint32_t)((u + BF_PD) / UT), t1 - 1), (u + BF_PD) % UT,
                                         (slot + BF_PD) % BF_NBUF);
                         }
                         if (kk + BF_READ_AHEAD < 8) read_frags(a[(kk + BF_READ_AHEAD) % 4], slot, kk + BF_READ_AHEAD);

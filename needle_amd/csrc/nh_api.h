@@ -83,6 +83,7 @@ struct needle_hip_index {
     float* d_norms = nullptr;      // [n_pad]
     uint32_t* d_valid = nullptr;   // live-row bitmask (by row id) or null
     float max_norm = 0.0f;
+    float bf16_err = 0.0f;         // max over rows of |row operand - its bf16 copy| (set with d_op_bf16); SQ8: max |code vector|
     std::mutex mu;
     // IVF
     needle_hip_index* centroids = nullptr;  // flat Euclidean index over the centroids (probing)
@@ -103,6 +104,7 @@ struct needle_hip_index {
     // per-search workspace (grow-only)
     nh::DevBuf w_qraw, w_qop, w_qn2, w_lists, w_lcnt, w_cand, w_candn, w_tau, w_flagged, w_flagcnt, w_filter, w_premax,
         w_tau0;
+    nh::DevBuf w_qerr;  // [q_pad] |query operand - its bf16 copy|
     nh::DevBuf r_idx, r_q, r_ids, r_dists, r_cnt;  // queries a reduced-precision pass could not decide, re-run in fp32
     nh::DevBuf x_keys, x_u32, x_u64, x_sel, x_mask;
     nh::DevBuf v_probe_ids, v_probe_d, v_probe_n, v_probe32, v_items, v_itemq;

@@ -56,6 +56,40 @@ __device__ inline bool bit_set(const uint32_t* __restrict__ mask, uint32_t i) {
     return (mask[i >> 5] >> (i & 31)) & 1u;
 }
 
+// Rounding the operands to bf16 moves a first-pass score by at most
+//     |dq| |b| + |q~| |db|  <=  qerr * B + (Q + qerr) * berr
+// (dq, db = operand minus its bf16 copy, measured when the copies are made; Q, B = operand norms: 1 for the
+// unit-normalised cosine operands, |q| and max |row| otherwise).  0 for f32 operands (qerr < 0).
+__host__ __device__ inline double bf16_score_err(int metric, double qn, double bmax, double qerr, double berr) {
+    if (qerr < 0.0) return 0.0;
+    const double Q = metric == NEEDLE_METRIC_COSINE ? 1.000001 : qn, B = metric == NEEDLE_METRIC_COSINE ? 1.000001 : bmax;
+    return 1.000001 * (qerr * B + (Q + qerr) * berr);
+}
+// Largest amount by which a first-pass score can differ from the exactly computed value of the same
+// expression, in score units (u = 2^-24; a D-term product sum errs by at most D u sum|x y| in any
+// order).  qn = |q|, bmax = max |row|, lowp = bf16_score_err(...).
+__host__ __device__ inline double score_eps(int metric, double lowp, double qn, double bmax, uint32_t dim) {
+    const double u = 5.9604644775390625e-08;
+    const double gam = 2.0 * ((double)dim + 16.0) * u;
+    switch (metric) {
+    case NEEDLE_METRIC_COSINE: return lowp + 2.0 * gam;
+    case NEEDLE_METRIC_EUCLIDEAN: return lowp + gam * qn * bmax + gam * 0.5 * bmax * bmax;
+    default: return lowp + 2.0 * gam * qn * bmax;
+    }
+}
+// the same for scalar-quantized rows (score = sum (q/scale) c - |v|^2/2): qconst = |q|^2 - 2 q.min, vmax = max |v|,
+// mnorm = |min_vals|; with a bf16 query operand qs_err2 = |q/scale - bf16(q/scale)|^2 and cmax = max |code vector|
+// (the codes themselves are exact in bf16), else qs_err2 < 0
+__host__ __device__ inline double score_eps_sq8(double qconst, double vmax, double mnorm, uint32_t dim, double qs_err2,
+                                                double cmax) {
+    const double u = 5.9604644775390625e-08;
+    const double gam = 2.0 * ((double)dim + 16.0) * u;
+    const double qn = mnorm + sqrt(mnorm * mnorm + fabs(qconst));
+    double e = gam * (qn * (vmax + mnorm) + 0.5 * vmax * vmax);
+    if (qs_err2 >= 0.0) e += 1.000001 * sqrt(qs_err2) * cmax;
+    return e;
+}
+
 // One unit of the inverted-list scan.
 struct IvfItem {
     uint32_t tile0, tile1;   // row tiles [tile0, tile1) of the list (lists are padded to whole tiles)
@@ -73,7 +107,8 @@ struct ScanParams {
     uint32_t* list_counts;    // [q_pad][n_splits]
     uint32_t n;               // real rows
     uint32_t n_tiles;         // ceil(n / TILE_ROWS)
-    uint32_t tiles_per_split;
+    uint32_t tiles_per_split; // slice s owns tiles s, s + n_splits, s + 2 n_splits, ... (at most tiles_per_split of them):
+                              // rows that arrive clustered are spread over all slices
     uint32_t n_splits;
     uint32_t q_tiles;         // q_pad / queries per workgroup
     uint32_t n_queries;       // real queries; the padding slots up to q_pad never list a candidate
@@ -88,6 +123,7 @@ struct ScanParams {
     float* pre_max;           // [q_pad][8 * n_splits] (pre-pass output)
     const float* tau0;        // [q_pad] starting threshold of the main pass, or null
     uint32_t pre_tiles;
+    uint32_t pre_stride;      // the pre-pass samples every pre_stride-th tile of a slice
     uint32_t kseed;           // rank of the seeded threshold among the sampled group maxima (k <= kseed <= kprime)
     // a launch may cover only tiles [tile_off, tile_off + tile_len) of every slice; `resume` continues the
     // candidate lists of the launch before it (counts are read back), with thresholds refreshed in between

@@ -6,10 +6,22 @@ namespace nh {
 
 // ---- flat_scan.hip ---------------------------------------------------------
 hipError_t launch_flat_scan(int precision, const ScanParams& p, hipStream_t stream);
-// pre-pass over p.pre_tiles tiles per slice (writes p.pre_max), then d_tau0[q_pad]
-hipError_t launch_flat_prepass(int precision, const ScanParams& p, float* d_tau0, hipStream_t stream);
-// between two launches sharing lists: d_tau[q] = max(d_tau[q], kseed-th largest score listed for q so far)
-hipError_t launch_tau_refresh(const ScanParams& p, uint32_t n_lists, float* d_tau, hipStream_t stream);
+// What the threshold refresh needs to size the uncertainty band of a query's scores (see score_eps).
+struct TauBand {
+    const double* qn2;   // [q] |q|^2 (SQ8: qconst)
+    const double* qs2;   // SQ8 with bf16 query operand: [q] |q/scale - bf16(q/scale)|^2, else null
+    const float* qerr;   // bf16 operands: [q] |query operand - its bf16 copy|, else null
+    double berr;         // bf16 operands: max over rows of |row operand - its bf16 copy|; SQ8: max |code vector|
+    double bmax, mnorm;  // max row norm; SQ8: |min_vals|
+    uint32_t dim;
+    int metric, precision, sq8;
+};
+// pre-pass over p.pre_tiles tiles per slice (writes p.pre_max), then d_tau0[q_pad] = the kseed-th largest group
+// maximum minus twice the score uncertainty
+hipError_t launch_flat_prepass(int precision, const ScanParams& p, float* d_tau0, const TauBand& band, hipStream_t stream);
+// between two launches sharing lists: d_tau[q] = max(d_tau[q], kseed-th largest score listed for q so far
+// minus twice the score uncertainty)
+hipError_t launch_tau_refresh(const ScanParams& p, uint32_t n_lists, float* d_tau, const TauBand& band, hipStream_t stream);
 // inverted-list scan: one workgroup per p.items[i]
 hipError_t launch_ivf_scan(int precision, const ScanParams& p, uint32_t n_items, hipStream_t stream);
 int flat_scan_blocks_per_cu(int precision);
@@ -33,23 +45,33 @@ hipError_t launch_flat_scan_bf16(const ScanParams& p, bool prepass, hipStream_t 
 hipError_t launch_row_prep(const float* d_rows, uint64_t n, uint32_t dim, uint32_t dpad,
                            bool normalize, float* d_op_f32, uint16_t* d_op_bf16, float* d_cinit,
                            float* d_norms, double* d_norm2, uint32_t* d_max_norm_bits,
-                           hipStream_t stream);
+                           float* d_bf16_err /* [n] |operand - bf16 operand|, nullable */,
+                           uint32_t* d_max_bf16_err_bits /* running maximum of it, nullable */, hipStream_t stream);
 // 0 if every value is finite, else 1 + index of the first row holding a NaN / Inf.
 hipError_t launch_validate_rows(const float* d_rows, uint64_t n, uint32_t dim, uint32_t* d_bad_row_plus1,
                                 hipStream_t stream);
 
-// Scalar-quantized index build: per row -|v|^2/2 (v = decoded row) and the running max |v|.
+// Scalar-quantized index build: per row -|v|^2/2 (v = decoded row); d_max_norm_bits[0] = running max |v|,
+// d_max_norm_bits[1] = running max |code vector|.
 hipError_t launch_sq8_row_prep(const uint8_t* d_codes, uint64_t n, uint32_t dim, uint32_t stride, const float* d_min,
                                const float* d_scale, float* d_cinit, uint32_t* d_max_norm_bits, hipStream_t stream);
-// Scalar-quantized query upload: q_op = q / scale (zero padded to dpad), qconst = sum(q^2 - 2 q min).
+// Scalar-quantized query upload: q_op = q / scale (zero padded to dpad; f32 and/or bf16 copy),
+// qconst = sum(q^2 - 2 q min), qscaled_err2 = |q/scale - bf16(q/scale)|^2 (nullable, with the bf16 copy).
 hipError_t launch_sq8_query_prep(const float* d_queries, uint32_t q, uint32_t dim, uint32_t dpad, const float* d_min,
-                                 const float* d_scale, float* d_qop, double* d_qconst, hipStream_t stream);
+                                 const float* d_scale, float* d_qop, uint16_t* d_qop_bf16, double* d_qconst,
+                                 double* d_qscaled_err2, hipStream_t stream);
+// bf16 operand copy [n][dpad] of a u8 code matrix [n][stride] (exact); d_out is zero-filled by the caller.
+hipError_t launch_sq8_codes_bf16(const uint8_t* d_codes, uint64_t n, uint32_t dim, uint32_t stride, uint32_t dpad,
+                                 uint16_t* d_out, hipStream_t stream);
 
 // ---- flat_post.hip ---------------------------------------------------------
 struct PostParams {
     const float* base_raw;    // [n][dim] original rows
     const float* query_raw;   // [q][dim] original queries
     const double* qnorm2;     // [q] |q|^2
+    const double* qaux;       // SQ8 with bf16 operands: [q] |q/scale - bf16(q/scale)|^2, else null
+    const float* qerr;        // bf16 operands: [q] |query operand - its bf16 copy|, else null
+    double berr;              // bf16 operands: max |row operand - its bf16 copy|; SQ8: max |code vector|
     const uint2* lists;
     const uint32_t* list_counts;
     uint32_t* cand_ids;       // [q][kprime]
@@ -88,10 +110,11 @@ struct PqScanParams {
     const float* queries;      // [q][dim] raw
     const uint32_t* valid;
     const uint32_t* filter;
-    uint2* lists;              // [q][n_splits * 4][cap]  (bits of -distance, row)
-    uint32_t* list_counts;     // [q][n_splits * 4]
+    uint2* lists;              // [q][n_splits * PQ_WAVES][cap]  (bits of -distance, row)
+    uint32_t* list_counts;     // [q][n_splits * PQ_WAVES]
     uint32_t n, m, dsub, dim, q, qg, n_splits, rows_per_split, k, cap;
 };
+constexpr int PQ_WAVES = 16;   // waves per workgroup sharing the resident tables; one candidate list per wave
 hipError_t launch_pq_scan(const PqScanParams& p, hipStream_t stream);
 uint32_t pq_scan_queries_per_block(uint32_t m);
 

@@ -19,7 +19,9 @@ __global__ __launch_bounds__(256) void row_prep_kernel(const float* __restrict__
                                                        float* __restrict__ cinit,
                                                        float* __restrict__ norms,
                                                        double* __restrict__ norm2,
-                                                       uint32_t* __restrict__ max_norm_bits) {
+                                                       uint32_t* __restrict__ max_norm_bits,
+                                                       float* __restrict__ bf16_err,
+                                                       uint32_t* __restrict__ max_bf16_err_bits) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t row = (uint64_t)blockIdx.x * 4 + wave;
     if (row >= n) return;
@@ -30,10 +32,23 @@ __global__ __launch_bounds__(256) void row_prep_kernel(const float* __restrict__
     const float norm = (float)sqrt(s);
     float inv = 1.0f;
     if (normalize) inv = (s > 0.0) ? (float)(1.0 / sqrt(s)) : 0.0f;
+    double err = 0.0;  // |operand - bf16(operand)|^2
     for (uint32_t i = lane; i < dim; i += 64) {
         const float v = src[i] * inv;
         if (op_f32) op_f32[row * dpad + i] = v;
-        if (op_bf16) op_bf16[row * dpad + i] = bf16_rne(v);
+        if (op_bf16) {
+            const uint16_t b = bf16_rne(v);
+            op_bf16[row * dpad + i] = b;
+            const double e = (double)v - (double)__uint_as_float((uint32_t)b << 16);
+            err += e * e;
+        }
+    }
+    if (op_bf16 && (bf16_err || max_bf16_err_bits)) {
+        for (int off = 32; off; off >>= 1) err += __shfl_xor(err, off);
+        // rounded up, so that the stored value is never below the true one
+        const float ef = __uint_as_float(__float_as_uint((float)sqrt(err)) + 2u);
+        if (lane == 0 && bf16_err) bf16_err[row] = ef;
+        if (lane == 0 && max_bf16_err_bits) atomicMax(max_bf16_err_bits, __float_as_uint(ef));
     }
     if (lane == 0) {
         if (norms) norms[row] = norm;
@@ -49,11 +64,13 @@ __global__ __launch_bounds__(256) void row_prep_kernel(const float* __restrict__
 
 hipError_t launch_row_prep(const float* d_rows, uint64_t n, uint32_t dim, uint32_t dpad, bool normalize,
                            float* d_op_f32, uint16_t* d_op_bf16, float* d_cinit, float* d_norms,
-                           double* d_norm2, uint32_t* d_max_norm_bits, hipStream_t stream) {
+                           double* d_norm2, uint32_t* d_max_norm_bits, float* d_bf16_err, uint32_t* d_max_bf16_err_bits,
+                           hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const uint32_t grid = (uint32_t)((n + 3) / 4);
     hipLaunchKernelGGL(row_prep_kernel, dim3(grid), dim3(256), 0, stream, d_rows, n, dim, dpad,
-                       normalize ? 1 : 0, d_op_f32, d_op_bf16, d_cinit, d_norms, d_norm2, d_max_norm_bits);
+                       normalize ? 1 : 0, d_op_f32, d_op_bf16, d_cinit, d_norms, d_norm2, d_max_norm_bits, d_bf16_err,
+                       d_max_bf16_err_bits);
     return hipGetLastError();
 }
 
@@ -72,21 +89,23 @@ __global__ __launch_bounds__(256) void validate_rows_kernel(const float* __restr
 __global__ __launch_bounds__(256) void sq8_row_prep_kernel(const uint8_t* __restrict__ codes, uint64_t n, uint32_t dim,
                                                            uint32_t stride, const float* __restrict__ mins,
                                                            const float* __restrict__ scale, float* __restrict__ cinit,
-                                                           uint32_t* __restrict__ max_norm_bits) {
+                                                           uint32_t* __restrict__ max_norm_bits) {  // [0] max |v|, [1] max |codes|
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t row = (uint64_t)blockIdx.x * 4 + wave;
     if (row >= n) return;
     const uint8_t* c = codes + row * stride;
-    double s = 0.0;
+    double s = 0.0, cc = 0.0;
     for (uint32_t i = lane; i < dim; i += 64) {
         const float v = ((float)c[i] / scale[i]) + mins[i];
         s += (double)v * (double)v;
+        cc += (double)c[i] * (double)c[i];
     }
-    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+    for (int off = 32; off; off >>= 1) { s += __shfl_xor(s, off); cc += __shfl_xor(cc, off); }
     if (lane == 0) {
         cinit[row] = -(float)(0.5 * s);
         const float norm = (float)sqrt(s);
         atomicMax(max_norm_bits, __float_as_uint(norm) + 1u);
+        atomicMax(max_norm_bits + 1, __float_as_uint((float)sqrt(cc)) + 1u);
     }
 }
 
@@ -101,26 +120,53 @@ hipError_t launch_sq8_row_prep(const uint8_t* d_codes, uint64_t n, uint32_t dim,
 __global__ __launch_bounds__(256) void sq8_query_prep_kernel(const float* __restrict__ queries, uint32_t q, uint32_t dim,
                                                              uint32_t dpad, const float* __restrict__ mins,
                                                              const float* __restrict__ scale, float* __restrict__ qop,
-                                                             double* __restrict__ qconst) {
+                                                             uint16_t* __restrict__ qop_bf16, double* __restrict__ qconst,
+                                                             double* __restrict__ qscaled_err2) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t row = blockIdx.x * 4 + wave;
     if (row >= q) return;
     const float* src = queries + (uint64_t)row * dim;
-    double s = 0.0;
+    double s = 0.0, t = 0.0;
     for (uint32_t i = lane; i < dim; i += 64) {
         const float x = src[i];
-        qop[(uint64_t)row * dpad + i] = x / scale[i];
+        const float xs = x / scale[i];
+        if (qop) qop[(uint64_t)row * dpad + i] = xs;
+        if (qop_bf16) {
+            const uint16_t b = bf16_rne(xs);
+            qop_bf16[(uint64_t)row * dpad + i] = b;
+            const double e = (double)xs - (double)__uint_as_float((uint32_t)b << 16);
+            t += e * e;  // |q/scale - bf16(q/scale)|^2
+        }
         s += (double)x * (double)x - 2.0 * (double)x * (double)mins[i];
     }
-    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) qconst[row] = s;
+    for (int off = 32; off; off >>= 1) { s += __shfl_xor(s, off); t += __shfl_xor(t, off); }
+    if (lane == 0) {
+        qconst[row] = s;
+        if (qscaled_err2) qscaled_err2[row] = t;
+    }
 }
 
 hipError_t launch_sq8_query_prep(const float* d_queries, uint32_t q, uint32_t dim, uint32_t dpad, const float* d_min,
-                                 const float* d_scale, float* d_qop, double* d_qconst, hipStream_t stream) {
+                                 const float* d_scale, float* d_qop, uint16_t* d_qop_bf16, double* d_qconst,
+                                 double* d_qscaled_err2, hipStream_t stream) {
     if (q == 0) return hipSuccess;
     hipLaunchKernelGGL(sq8_query_prep_kernel, dim3((q + 3) / 4), dim3(256), 0, stream, d_queries, q, dim, dpad, d_min,
-                       d_scale, d_qop, d_qconst);
+                       d_scale, d_qop, d_qop_bf16, d_qconst, d_qscaled_err2);
+    return hipGetLastError();
+}
+
+// bf16 operand copy of a code matrix: every u8 value is exact in bf16
+__global__ __launch_bounds__(256) void sq8_codes_bf16_kernel(const uint8_t* __restrict__ codes, uint64_t n, uint32_t dim,
+                                                             uint32_t stride, uint32_t dpad, uint16_t* __restrict__ out) {
+    const uint64_t row = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < dim; i += 256)
+        out[row * dpad + i] = (uint16_t)(__float_as_uint((float)codes[row * stride + i]) >> 16);
+}
+
+hipError_t launch_sq8_codes_bf16(const uint8_t* d_codes, uint64_t n, uint32_t dim, uint32_t stride, uint32_t dpad,
+                                 uint16_t* d_out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(sq8_codes_bf16_kernel, dim3((uint32_t)n), dim3(256), 0, stream, d_codes, n, dim, stride, dpad, d_out);
     return hipGetLastError();
 }
 

@@ -92,6 +92,7 @@ def test_sq8_asymmetric_scan(ctx, oracle, shape):
     ix = Sq8Index(ctx, sq, codes)
     _cmp(ix.search(queries, k), osq.batch_search(queries, codes, k))
     _cmp(ix.search(queries[:5], k, precision="exact"), osq.batch_search(queries[:5], codes, k))
+    _cmp(ix.search(queries, k, precision="bf16"), osq.batch_search(queries, codes, k))  # bf16 query operand, exact codes
     ix.close()
 
 
@@ -116,4 +117,8 @@ def test_sq8_masks_duplicates_and_constant_dims(ctx, oracle):
     assert ctx.metrics()["fallback_queries"] >= 1
     filt = (np.arange(n) % 7) == 0
     _cmp(ix.search(queries, 10, filter_mask=filt), osq.batch_search(queries, codes, 10, valid=valid & filt))
+    ctx.reset_metrics()
+    _cmp(ix.search(queries, 10, precision="bf16"), osq.batch_search(queries, codes, 10, valid=valid))
+    m2 = ctx.metrics()
+    assert m2["refined_queries"] + m2["fallback_queries"] >= 1  # the duplicate cluster goes down the refinement chain
     ix.close()

