@@ -167,7 +167,7 @@ void nh::index_free(needle_hip_index* ix) {
     for (DevBuf* b : {&ix->w_qraw, &ix->w_qop, &ix->w_qn2, &ix->w_lists, &ix->w_lcnt, &ix->w_cand, &ix->w_candn,
                       &ix->w_tau, &ix->w_flagged, &ix->w_flagcnt, &ix->w_filter, &ix->w_premax, &ix->w_tau0, &ix->x_keys, &ix->x_u32,
                       &ix->x_u64, &ix->x_sel, &ix->x_mask, &ix->v_probe_ids, &ix->v_probe_d, &ix->v_probe_n, &ix->v_probe32,
-                      &ix->v_items, &ix->v_itemq, &ix->w_qerr, &ix->r_idx, &ix->r_q, &ix->r_ids, &ix->r_dists, &ix->r_cnt})
+                      &ix->v_items, &ix->v_itemq, &ix->v_lbase, &ix->w_qerr, &ix->r_idx, &ix->r_q, &ix->r_ids, &ix->r_dists, &ix->r_cnt})
         b->release();
     delete ix;
 }
@@ -429,7 +429,7 @@ needle_hip_status nh::run_exact(needle_hip_index* ix, const float* d_queries, co
 }
 
 // The bf16 operand copy is built on the first bf16 search of an index (callers hold ix->mu).
-static needle_hip_status ensure_bf16_copy(needle_hip_index* ix) {
+needle_hip_status nh::ensure_bf16_copy(needle_hip_index* ix) {
     if (ix->d_op_bf16) return NEEDLE_HIP_OK;
     needle_hip_ctx* c = ix->ctx;
     ix->dpad_bf16 = flat_scan_bf16_dpad(ix->dim);
@@ -444,7 +444,8 @@ static needle_hip_status ensure_bf16_copy(needle_hip_index* ix) {
     if (e == hipSuccess && sq8)  // codes are exact in bf16; ix->bf16_err already holds max |code vector|
         e = launch_sq8_codes_bf16(ix->d_codes, ix->n, ix->dim, ix->dpad_f32, ix->dpad_bf16, d, c->stream);
     else if (e == hipSuccess)
-        e = launch_row_prep(ix->d_raw, ix->n, ix->dim, ix->dpad_bf16, ix->metric == NEEDLE_METRIC_COSINE, nullptr, d,
+        e = launch_row_prep(ix->d_raw, ix->kind == KIND_IVF ? ix->n_pad : ix->n, ix->dim, ix->dpad_bf16,
+                            ix->metric == NEEDLE_METRIC_COSINE, nullptr, d,
                             nullptr, nullptr, nullptr, nullptr, nullptr, d_bits, c->stream);
     uint32_t bits = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&bits, d_bits, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
@@ -498,12 +499,19 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
         }
     }
     const size_t elt = bf16 ? 2 : 4;
-    const uint32_t n_lists = plan.n_splits * lists_per_split;  // per query
+    // Small bases (the centroid set of an IVF index, k-means assignment): with few rows per query the candidate
+    // lists would hold a large part of the base.  The scan then writes the whole score matrix and a selection
+    // kernel takes the kprime best of every row.
+    const bool dense = bf16 && ix->n_pad <= DENSE_MAX_ROWS && !(getenv("NEEDLE_HIP_DEBUG_NODENSE"));
+    const uint32_t n_lists = dense ? 1 : plan.n_splits * lists_per_split;  // per query
+    if (dense) HIP_TRY(ix->w_scores.ensure((size_t)q_pad * ix->n_pad * sizeof(float)));
 
     HIP_TRY(ix->w_qop.ensure((size_t)q_pad * dpad * elt));
     HIP_TRY(ix->w_qn2.ensure((size_t)q_pad * 2 * sizeof(double)));  // second half: SQ8 |q / scale|^2
-    HIP_TRY(ix->w_lists.ensure((size_t)q_pad * n_lists * cap * sizeof(uint2)));
-    HIP_TRY(ix->w_lcnt.ensure((size_t)q_pad * n_lists * sizeof(uint32_t)));
+    if (!dense) {
+        HIP_TRY(ix->w_lists.ensure((size_t)q_pad * n_lists * cap * sizeof(uint2)));
+        HIP_TRY(ix->w_lcnt.ensure((size_t)q_pad * n_lists * sizeof(uint32_t)));
+    }
     HIP_TRY(ix->w_cand.ensure((size_t)q * kprime * sizeof(uint32_t)));
     HIP_TRY(ix->w_candn.ensure((size_t)q * sizeof(uint32_t)));
     HIP_TRY(ix->w_tau.ensure((size_t)q * sizeof(float)));
@@ -552,7 +560,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     sp.kseed = std::min<uint32_t>(kprime, std::min(k, n) + 6);
     if (const char* e = getenv("NEEDLE_HIP_DEBUG_PRE")) pre_tiles = std::min<uint32_t>((uint32_t)atoi(e), plan.tiles_per_split);
     if (const char* e = getenv("NEEDLE_HIP_DEBUG_KSEED")) sp.kseed = std::min<uint32_t>(std::max<uint32_t>((uint32_t)atoi(e), std::min(k, n)), kprime);
-    const bool seeded = pre_tiles >= 1 && !(sp.debug & 2u);
+    const bool seeded = pre_tiles >= 1 && !(sp.debug & 2u) && !dense;
     TauBand band{};
     band.qn2 = ix->w_qn2.as<double>();
     band.qs2 = (sq8 && bf16) ? ix->w_qn2.as<double>() + q_pad : nullptr;
@@ -582,6 +590,12 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
         stages[1] = plan.tiles_per_split / 4;
         stages[2] = plan.tiles_per_split - stages[0] - stages[1];
     }
+    if (dense) {
+        sp.dense_scores = ix->w_scores.as<float>();
+        sp.dense_ld = ix->n_pad;
+        HIP_TRY(launch_dense_scores_bf16(sp, c->stream));
+        stages[0] = 0;
+    }
     for (int r = 0; r < 3 && stages[r] > 0; ++r) {
         if (r > 0) {
             HIP_TRY(launch_tau_refresh(sp, n_lists, ix->w_tau0.as<float>(), band, c->stream));
@@ -606,7 +620,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
             fprintf(stderr, "[needle_hip] in-kernel clock: median %.3f GHz (min %.3f, max %.3f), mean block cycles %.0f\n",
                     ghz[ghz.size() / 2], ghz.front(), ghz.back(), cyc / ghz.size());
     }
-    if (sp.debug & 8u) {  // development: how many candidates did the first pass list?
+    if ((sp.debug & 8u) && !dense) {  // development: how many candidates did the first pass list?
         std::vector<uint32_t> lc((size_t)q_pad * n_lists);
         HIP_TRY(hipMemcpyAsync(lc.data(), sp.list_counts, lc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -645,7 +659,15 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
         pp.aux_norm = (float)(ix->sq_min_norm * (1.0 + 1e-6));
         if (bf16) pp.qaux = ix->w_qn2.as<double>() + q_pad;
     }
-    HIP_TRY(launch_merge_select(pp, c->stream));
+    if (dense) {
+        pp.dense_scores = sp.dense_scores;
+        pp.dense_ld = sp.dense_ld;
+        pp.valid = ix->d_valid;
+        pp.filter = d_filter;
+        HIP_TRY(launch_dense_select(pp, c->stream));
+    } else {
+        HIP_TRY(launch_merge_select(pp, c->stream));
+    }
     HIP_TRY(launch_rescore_finalize(pp, c->stream));
 
     uint32_t n_flagged = 0;

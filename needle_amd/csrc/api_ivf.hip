@@ -16,6 +16,8 @@
 //      check, exact scan of the probed lists for rejected queries (flat_post.hip)
 #include "nh_api.h"
 
+#include <chrono>
+
 using namespace nh;
 
 __global__ __launch_bounds__(256) void ivf_gather_rows_kernel(const float* __restrict__ src,
@@ -36,6 +38,63 @@ __global__ __launch_bounds__(256) void ivf_gather_rows_kernel(const float* __res
 __global__ void ivf_narrow_probe_kernel(const uint64_t* __restrict__ ids, uint32_t total, uint32_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) out[i] = (uint32_t)ids[i];  // padding UINT64_MAX -> UINT32_MAX
+}
+
+// Starting thresholds of the list scan.  One wave per query scores (up to) the first IVF_SEED_ROWS rows of the
+// query's nearest list with plain vector arithmetic, in the first pass's score units (q.b - |b|^2/2), and takes
+// the kseed-th largest score of live rows minus twice the score uncertainty: kseed live rows reach it, so the
+// scan may start from it (a lower rank or a shorter sample only makes the threshold weaker, never wrong).
+constexpr uint32_t IVF_SEED_ROWS = 512;
+
+__global__ __launch_bounds__(64) void ivf_seed_tau_kernel(const float* __restrict__ queries, const float* __restrict__ rows,
+                                                          const float* __restrict__ cinit, const uint32_t* __restrict__ probe,
+                                                          const uint32_t* __restrict__ probe_n, uint32_t np,
+                                                          const uint32_t* __restrict__ list_pos,
+                                                          const uint32_t* __restrict__ list_len,
+                                                          const uint32_t* __restrict__ pos2id, const uint32_t* __restrict__ valid,
+                                                          const uint32_t* __restrict__ filter, uint32_t dim, uint32_t kseed,
+                                                          nh::TauBand band, float* __restrict__ tau) {
+    __shared__ uint32_t ord[IVF_SEED_ROWS];
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    float t = -INFINITY;
+    if (probe_n[q] > 0) {
+        const uint32_t l = probe[(uint64_t)q * np];
+        const uint32_t p0 = list_pos[l], len = min(list_len[l], IVF_SEED_ROWS);
+        const float* qv = queries + (uint64_t)q * dim;
+        uint32_t live = 0;
+        for (uint32_t r = 0; r < len; ++r) {
+            const float* b = rows + (uint64_t)(p0 + r) * dim;
+            float s = 0.0f;
+            for (uint32_t i = lane; i < dim; i += 64) s += qv[i] * b[i];
+            for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+            const uint32_t id = pos2id[p0 + r];
+            bool ok = id != 0xffffffffu;
+            if (ok && valid) ok = nh::bit_set(valid, id);
+            if (ok && filter) ok = nh::bit_set(filter, id);
+            if (ok) {  // wave-uniform
+                if (lane == 0) ord[live] = nh::f2ord(s + cinit[p0 + r]);
+                live += 1;
+            }
+        }
+        __syncthreads();
+        if (live >= kseed) {
+            uint32_t prefix = 0;
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t trial = prefix | (1u << bit);
+                uint32_t cnt = 0;
+                for (uint32_t i = 0; i < live; i += 64) {
+                    const bool ge = (i + lane < live) && (ord[i + lane] >= trial);
+                    cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ge));
+                }
+                if (cnt >= kseed) prefix = trial;
+            }
+            const double qn = sqrt(band.qn2[q]);
+            const double lowp = nh::bf16_score_err(band.metric, qn, band.bmax, band.qerr ? (double)band.qerr[q] : -1.0, band.berr);
+            const float tb = (float)((double)nh::ord2f(prefix) - 2.0 * nh::score_eps(band.metric, lowp, qn, band.bmax, band.dim));
+            if (tb == tb) t = tb;
+        }
+    }
+    if (lane == 0) tau[q] = t;
 }
 
 extern "C" needle_hip_status needle_hip_ivf_build(needle_hip_ctx* c, const float* base, uint64_t n, uint32_t dim,
@@ -152,7 +211,8 @@ static needle_hip_status ivf_probe_device(needle_hip_index* ix, const float* d_q
     HIP_TRY(ix->v_probe32.ensure((size_t)q * np * sizeof(uint32_t)));
     {
         std::lock_guard<std::mutex> g(ix->centroids->mu);
-        ST_TRY(flat_search_batch_device(ix->centroids, d_queries, q, np, NEEDLE_PRECISION_FP32, nullptr,
+        // bf16 first pass over the centroids: the probe lists it returns are the exact ones all the same
+        ST_TRY(flat_search_batch_device(ix->centroids, d_queries, q, np, NEEDLE_PRECISION_BF16, nullptr,
                                         ix->v_probe_ids.as<uint64_t>(), ix->v_probe_d.as<float>(),
                                         ix->v_probe_n.as<uint32_t>()));
     }
@@ -194,6 +254,7 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
                                               uint32_t nprobe, int precision, const uint32_t* d_filter,
                                               uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts) {
     needle_hip_ctx* c = ix->ctx;
+    const double t_entry = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
     const uint32_t np = std::min(nprobe, ix->nlist);
     if (np == 0) {  // no list probed: no candidates
         HIP_TRY(launch_fill_empty(d_out_ids, d_out_dists, d_out_counts, q, k, c->stream));
@@ -205,9 +266,13 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     const uint32_t* d_probe = ix->v_probe32.as<uint32_t>();
     const uint32_t* d_probe_n = ix->v_probe_n.as<uint32_t>();
 
-    const uint32_t kprime = choose_kprime(std::min<uint64_t>(k, ix->n), precision);
-    const bool exact_only = precision == NEEDLE_PRECISION_EXACT_SCAN || kprime > KPRIME_MAX ||
-                            (uint64_t)np * kprime * sizeof(uint64_t) > 60000ull;
+    // bf16 is a hint, as in the flat search: dimensions beyond the register-resident query block use fp32
+    bool bf16 = precision == NEEDLE_PRECISION_BF16 && flat_scan_bf16_dpad(ix->dim) != 0;
+    if (bf16 && choose_kprime((uint32_t)std::min<uint64_t>(k, ix->n), NEEDLE_PRECISION_BF16) > KPRIME_MAX) bf16 = false;
+    const int scan_precision = bf16 ? NEEDLE_PRECISION_BF16 : NEEDLE_PRECISION_FP32;
+    const uint32_t lpe = bf16 ? 2 : 1;  // candidate lists per (query, list run): the bf16 kernel keeps one per lane half
+    const uint32_t kprime = choose_kprime((uint32_t)std::min<uint64_t>(k, ix->n), scan_precision);
+    const bool exact_only = precision == NEEDLE_PRECISION_EXACT_SCAN || kprime > KPRIME_MAX;
     if (exact_only) {
         ST_TRY(run_exact(ix, d_queries, nullptr, q, k, d_filter, d_out_ids, d_out_dists, d_out_counts, d_probe, d_probe_n, np));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -217,34 +282,101 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     }
 
     // regroup (query, probed list) pairs by list on the host: q * np small integers
+    const bool dbg_t = getenv("NEEDLE_HIP_DEBUG") && (atoi(getenv("NEEDLE_HIP_DEBUG")) & 8);
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    if (dbg_t) HIP_TRY(hipStreamSynchronize(c->stream));
+    const double t_probe_done = now();
     std::vector<uint32_t> probe((size_t)q * np), probe_n(q);
     HIP_TRY(hipMemcpyAsync(probe.data(), d_probe, probe.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(probe_n.data(), d_probe_n, (size_t)q * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    std::vector<uint32_t> per_list(ix->nlist + 1, 0);
-    for (uint32_t i = 0; i < q; ++i)
-        for (uint32_t s = 0; s < probe_n[i]; ++s) per_list[probe[(size_t)i * np + s] + 1] += 1;
-    for (uint32_t l = 0; l < ix->nlist; ++l) per_list[l + 1] += per_list[l];
-    std::vector<uint2> itemq(per_list[ix->nlist]);
-    {
-        std::vector<uint32_t> fill(per_list.begin(), per_list.end() - 1);
-        for (uint32_t i = 0; i < q; ++i)  // ascending query index inside a list
-            for (uint32_t s = 0; s < probe_n[i]; ++s) itemq[fill[probe[(size_t)i * np + s]]++] = make_uint2(i, s);
+    // Work items.  A list is cut into runs of at most `run` row tiles, so that a long list (hub centroid) becomes
+    // many workgroups instead of one long one; every (query, probed list, run) owns a candidate list of its own,
+    // numbered consecutively per query: query i owns lists list_base[i] .. list_base[i+1]-1.  `run` doubles until the
+    // lists of the busiest query fit the merge kernel's LDS.
+    // Thresholds start from a sample of every query's nearest list (ivf_seed_tau_kernel).  The probe slots are then
+    // scanned in up to three launches (by default slots 0-3, then the rest); after each launch a query's threshold
+    // is raised to the (k+6)-th best score it has listed, so the far lists only list what can still matter.
+    auto tiles_of = [&](uint32_t l) { return round_up(ix->list_len[l], TILE_ROWS) / TILE_ROWS; };
+    const uint32_t max_lists_per_query = std::max<uint32_t>(np, 2048);  // bounds the list bookkeeping, not correctness
+    const uint32_t item_queries = bf16 ? flat_scan_bf16_queries_per_block(flat_scan_bf16_dpad(ix->dim)) : (uint32_t)TILE_QUERIES;
+    uint32_t run = 8;
+    std::vector<uint32_t> list_base(q + 1, 0);
+    uint32_t busiest = 0;
+    for (;;) {
+        busiest = 0;
+        for (uint32_t i = 0; i < q; ++i) {
+            uint32_t cnt = 0;
+            for (uint32_t sl = 0; sl < probe_n[i]; ++sl) cnt += std::max<uint32_t>(1, (tiles_of(probe[(size_t)i * np + sl]) + run - 1) / run);
+            list_base[i + 1] = list_base[i] + cnt;
+            busiest = std::max(busiest, cnt);
+        }
+        if (busiest <= max_lists_per_query || run >= (1u << 20)) break;
+        run *= 2;
     }
+    const uint32_t total_lists = list_base[q] * lpe;  // device numbering: entry y owns lists lpe*y .. lpe*y + lpe-1
+    uint32_t bounds[4] = {0, 0, std::min<uint32_t>(4, np), np};  // with seeded thresholds: slots 0-3, refresh, the rest
+    if (const char* dbg = getenv("NEEDLE_HIP_DEBUG_IVF_STAGES")) {  // development: "a,b" = slot bounds of launches 1 and 2
+        unsigned a = 0, b = 0;
+        if (sscanf(dbg, "%u,%u", &a, &b) == 2) { bounds[1] = std::min<uint32_t>(a, np); bounds[2] = std::min<uint32_t>(std::max(a, b), np); }
+    }
+    std::vector<uint2> itemq;
     std::vector<IvfItem> items;
-    for (uint32_t l = 0; l < ix->nlist; ++l) {
-        const uint32_t cnt = per_list[l + 1] - per_list[l];
-        if (cnt == 0 || ix->list_len[l] == 0) continue;
-        const uint32_t t0 = ix->list_pos[l] / TILE_ROWS, t1 = t0 + round_up(ix->list_len[l], TILE_ROWS) / TILE_ROWS;
-        for (uint32_t o = 0; o < cnt; o += TILE_QUERIES)
-            items.push_back(IvfItem{t0, t1, per_list[l] + o, std::min<uint32_t>(TILE_QUERIES, cnt - o)});
+    uint32_t item_end[3] = {0, 0, 0};
+    std::vector<uint32_t> slot_first((size_t)q * np);  // first candidate list of (query, slot)
+    for (uint32_t i = 0; i < q; ++i) {
+        uint32_t at = list_base[i];
+        for (uint32_t sl = 0; sl < probe_n[i]; ++sl) {
+            slot_first[(size_t)i * np + sl] = at;
+            at += std::max<uint32_t>(1, (tiles_of(probe[(size_t)i * np + sl]) + run - 1) / run);
+        }
+    }
+    for (int r = 0; r < 3; ++r) {
+        const uint32_t s0 = bounds[r], s1 = bounds[r + 1];
+        if (s1 > s0) {
+            std::vector<uint32_t> per_list(ix->nlist + 1, 0);
+            for (uint32_t i = 0; i < q; ++i)
+                for (uint32_t sl = s0; sl < std::min(s1, probe_n[i]); ++sl) per_list[probe[(size_t)i * np + sl] + 1] += 1;
+            for (uint32_t l = 0; l < ix->nlist; ++l) per_list[l + 1] += per_list[l];
+            std::vector<uint2> pairs(per_list[ix->nlist]);  // (query, slot) by list, ascending query index inside a list
+            {
+                std::vector<uint32_t> fill(per_list.begin(), per_list.end() - 1);
+                for (uint32_t i = 0; i < q; ++i)
+                    for (uint32_t sl = s0; sl < std::min(s1, probe_n[i]); ++sl)
+                        pairs[fill[probe[(size_t)i * np + sl]]++] = make_uint2(i, sl);
+            }
+            for (uint32_t l = 0; l < ix->nlist; ++l) {
+                const uint32_t cnt = per_list[l + 1] - per_list[l];
+                if (cnt == 0 || ix->list_len[l] == 0) continue;
+                const uint32_t t0 = ix->list_pos[l] / TILE_ROWS, nt = tiles_of(l);
+                for (uint32_t ch = 0; ch * run < nt; ++ch) {
+                    const uint32_t base = (uint32_t)itemq.size();
+                    for (uint32_t e = 0; e < cnt; ++e) {
+                        const uint2 pr = pairs[per_list[l] + e];
+                        itemq.push_back(make_uint2(pr.x, slot_first[(size_t)pr.x * np + pr.y] + ch));
+                    }
+                    for (uint32_t o = 0; o < cnt; o += item_queries)
+                        items.push_back(IvfItem{t0 + ch * run, t0 + std::min(nt, (ch + 1) * run), base + o,
+                                                std::min<uint32_t>(item_queries, cnt - o)});
+                }
+            }
+        }
+        item_end[r] = (uint32_t)items.size();
     }
 
-    const uint32_t dpad = ix->dpad_f32, cap = list_cap(kprime);
-    HIP_TRY(ix->w_qop.ensure((size_t)q * dpad * sizeof(float)));
+    const double t_items_done = now();
+    if (bf16) ST_TRY(ensure_bf16_copy(ix));
+    const uint32_t dpad = bf16 ? ix->dpad_bf16 : ix->dpad_f32, cap = list_cap(kprime);
+    const size_t elt = bf16 ? 2 : 4;
+    HIP_TRY(ix->w_qop.ensure((size_t)q * dpad * elt));
     HIP_TRY(ix->w_qn2.ensure((size_t)q * sizeof(double)));
-    HIP_TRY(ix->w_lists.ensure((size_t)q * np * cap * sizeof(uint2)));
-    HIP_TRY(ix->w_lcnt.ensure((size_t)q * np * sizeof(uint32_t)));
+    if (bf16) HIP_TRY(ix->w_qerr.ensure((size_t)q * sizeof(float)));
+    HIP_TRY(ix->w_lists.ensure((size_t)std::max<uint32_t>(total_lists, 1) * cap * sizeof(uint2)));
+    HIP_TRY(ix->w_lcnt.ensure((size_t)std::max<uint32_t>(total_lists, 1) * sizeof(uint32_t)));
+    HIP_TRY(ix->v_lbase.ensure((size_t)(q + 1) * sizeof(uint32_t)));
+    std::vector<uint32_t> list_base_dev(q + 1);
+    for (uint32_t i = 0; i <= q; ++i) list_base_dev[i] = list_base[i] * lpe;
+    HIP_TRY(hipMemcpyAsync(ix->v_lbase.p, list_base_dev.data(), (size_t)(q + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(ix->w_cand.ensure((size_t)q * kprime * sizeof(uint32_t)));
     HIP_TRY(ix->w_candn.ensure((size_t)q * sizeof(uint32_t)));
     HIP_TRY(ix->w_tau.ensure((size_t)q * sizeof(float)));
@@ -256,14 +388,15 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
         HIP_TRY(hipMemcpyAsync(ix->v_items.p, items.data(), items.size() * sizeof(IvfItem), hipMemcpyHostToDevice, c->stream));
     if (!itemq.empty())
         HIP_TRY(hipMemcpyAsync(ix->v_itemq.p, itemq.data(), itemq.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(ix->w_qop.p, 0, (size_t)q * dpad * sizeof(float), c->stream));
-    HIP_TRY(hipMemsetAsync(ix->w_lcnt.p, 0, (size_t)q * np * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(ix->w_qop.p, 0, (size_t)q * dpad * elt, c->stream));
+    HIP_TRY(hipMemsetAsync(ix->w_lcnt.p, 0, (size_t)std::max<uint32_t>(total_lists, 1) * sizeof(uint32_t), c->stream));
     HIP_TRY(hipMemsetAsync(ix->w_flagcnt.p, 0, sizeof(uint32_t), c->stream));
-    HIP_TRY(launch_row_prep(d_queries, q, ix->dim, dpad, false, ix->w_qop.as<float>(), nullptr, nullptr, nullptr,
-                            ix->w_qn2.as<double>(), nullptr, nullptr, nullptr, c->stream));
+    HIP_TRY(launch_row_prep(d_queries, q, ix->dim, dpad, false, bf16 ? nullptr : ix->w_qop.as<float>(),
+                            bf16 ? ix->w_qop.as<uint16_t>() : nullptr, nullptr, nullptr, ix->w_qn2.as<double>(), nullptr,
+                            bf16 ? ix->w_qerr.as<float>() : nullptr, nullptr, c->stream));
 
     ScanParams sp{};
-    sp.base_op = ix->d_op_f32;
+    sp.base_op = bf16 ? (const void*)ix->d_op_bf16 : (const void*)ix->d_op_f32;
     sp.query_op = ix->w_qop.p;
     sp.cinit = ix->d_cinit;
     sp.valid = ix->d_valid;
@@ -278,9 +411,30 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     sp.items = ix->v_items.as<IvfItem>();
     sp.item_queries = ix->v_itemq.as<uint2>();
     sp.pos2id = ix->d_pos2id;
-    sp.nprobe = np;
+    sp.n_queries = q;
+    sp.kseed = std::min<uint32_t>(kprime, (uint32_t)std::min<uint64_t>(k, ix->n) + 6);
+    HIP_TRY(ix->w_tau0.ensure((size_t)q * sizeof(float)));
+    sp.tau0 = ix->w_tau0.as<float>();
+    TauBand band{};
+    band.qn2 = ix->w_qn2.as<double>();
+    band.bmax = ix->max_norm;
+    band.qerr = bf16 ? ix->w_qerr.as<float>() : nullptr;
+    band.berr = ix->bf16_err;
+    band.dim = ix->dim; band.metric = ix->metric; band.precision = scan_precision;
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    HIP_TRY(launch_ivf_scan(NEEDLE_PRECISION_FP32, sp, (uint32_t)items.size(), c->stream));
+    hipLaunchKernelGGL(ivf_seed_tau_kernel, dim3(q), dim3(64), 0, c->stream, d_queries, ix->d_raw, ix->d_cinit, d_probe, d_probe_n,
+                       np, ix->d_list_pos, ix->d_list_len, ix->d_pos2id, ix->d_valid, d_filter, ix->dim, sp.kseed, band,
+                       ix->w_tau0.as<float>());
+    HIP_TRY(hipGetLastError());
+    for (int r = 0; r < 3; ++r) {
+        const uint32_t i0 = r ? item_end[r - 1] : 0u, i1 = item_end[r];
+        if (i1 == i0) continue;
+        if (i0 > 0)
+            HIP_TRY(launch_tau_refresh(sp, busiest * lpe, ix->w_tau0.as<float>(), band, c->stream, ix->v_lbase.as<uint32_t>()));
+        ScanParams spr = sp;
+        spr.items = sp.items + i0;
+        HIP_TRY(launch_ivf_scan(scan_precision, spr, i1 - i0, c->stream));
+    }
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
 
     PostParams pp{};
@@ -289,24 +443,32 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     pp.qnorm2 = ix->w_qn2.as<double>();
     pp.lists = sp.lists;
     pp.list_counts = sp.list_counts;
+    pp.list_base = ix->v_lbase.as<uint32_t>();
     pp.cand_ids = ix->w_cand.as<uint32_t>();
     pp.cand_n = ix->w_candn.as<uint32_t>();
     pp.tau_star = ix->w_tau.as<float>();
+    pp.tau0 = sp.tau0;  // rows a launch did not list scored at most the threshold it started from
     pp.pos2id = ix->d_pos2id;
     pp.flagged = ix->w_flagged.as<uint32_t>();
     pp.flag_count = ix->w_flagcnt.as<uint32_t>();
     pp.out_ids = d_out_ids;
     pp.out_dists = d_out_dists;
     pp.out_counts = d_out_counts;
-    pp.q = q; pp.n = ix->n_pad; pp.dim = ix->dim; pp.k = k; pp.kprime = kprime; pp.cap = cap; pp.n_splits = np;
-    pp.metric = ix->metric; pp.arith = ix->arith; pp.precision = NEEDLE_PRECISION_FP32;
+    pp.q = q; pp.n = ix->n_pad; pp.dim = ix->dim; pp.k = k; pp.kprime = kprime; pp.cap = cap; pp.n_splits = busiest * lpe;
+    pp.metric = ix->metric; pp.arith = ix->arith; pp.precision = scan_precision;
     pp.max_norm = ix->max_norm;
+    pp.qerr = bf16 ? ix->w_qerr.as<float>() : nullptr;
+    pp.berr = ix->bf16_err;
     HIP_TRY(launch_merge_select(pp, c->stream));
     HIP_TRY(launch_rescore_finalize(pp, c->stream));
 
     uint32_t n_flagged = 0;
     HIP_TRY(hipMemcpyAsync(&n_flagged, pp.flag_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (dbg_t)
+        fprintf(stderr, "[needle_hip] ivf: %u queries, %zu items, %u candidate lists (busiest query %u, run %u tiles); probe %.2f ms, "
+                "host regroup %.2f ms, device scan+post %.2f ms, undecided %u\n", q, items.size(), total_lists, busiest, run,
+                t_probe_done - t_entry, t_items_done - t_probe_done, now() - t_items_done, n_flagged);
     if (c->profiling) {
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));

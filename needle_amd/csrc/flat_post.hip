@@ -15,50 +15,81 @@
 namespace nh {
 
 // ---------------------------------------------------------------------------
-// merge_select: one wave per query.  Gathers the query's n_splits candidate
-// lists into LDS, keeps the kprime best by first-pass score and records the
-// score of the last one kept (tau*): every row that is NOT a candidate scored
-// <= tau* in the first pass.  Fewer than kprime entries in total means no
-// slice discarded anything: every live row is a candidate, tau* = -inf.
+// merge_select: one wave per query.  Gathers the query's candidate lists into LDS, keeps the kprime best by
+// first-pass score and records the score of the last one kept (tau*): every row that is NOT a candidate scored
+// <= tau*.  Fewer than kprime entries in total means no list discarded anything: every listed row is a
+// candidate, tau* = the threshold the scan started from (or -inf).
+// The LDS holds MERGE_KEYS keys whatever the number of lists: the lists are taken in groups, and when the next
+// group would not fit, what has been gathered so far is first cut down to its kprime best (the cut only ever
+// removes keys below the final kprime-th one).
 // ---------------------------------------------------------------------------
+constexpr uint32_t MERGE_KEYS = 4096 + KPRIME_MAX;
+
+// kprime-th largest of keys[0 .. total) (total >= kprime), found bit by bit; all keys are distinct
+__device__ inline uint64_t wave_kth_largest_lds(const uint64_t* keys, uint32_t total, uint32_t kprime, uint32_t lane) {
+    uint64_t prefix = 0;
+    for (int bit = 63; bit >= 0; --bit) {
+        const uint64_t trial = prefix | (1ull << bit);
+        uint32_t cnt = 0;
+        for (uint32_t i = 0; i < total; i += 64) {
+            const bool ge = (i + lane < total) && (keys[i + lane] >= trial);
+            cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ge));
+        }
+        if (cnt >= kprime) prefix = trial;
+    }
+    return prefix;
+}
+
 __global__ __launch_bounds__(64) void merge_select_kernel(PostParams p) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t mkeys[];
+    __shared__ __attribute__((aligned(16))) uint64_t mkeys[MERGE_KEYS];
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    const uint64_t first = p.list_base ? p.list_base[q] : (uint64_t)q * p.n_splits;
+    const uint32_t n_lists = p.list_base ? p.list_base[q + 1] - p.list_base[q] : p.n_splits;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    // lists per group: their entries (<= kprime each) fit beside kprime kept keys
+    const uint32_t group = min(64u, max(1u, (MERGE_KEYS - p.kprime) / p.kprime));
     uint32_t total = 0;
-    // lane l copies list l0 + l: the lists are short, so the 64 copies run side by side
-    for (uint32_t l0 = 0; l0 < p.n_splits; l0 += 64) {
+    for (uint32_t l0 = 0; l0 < n_lists; l0 += group) {
+        // lane l copies list l0 + l: the lists are short, so the copies run side by side
         const uint32_t li = l0 + lane;
-        const uint32_t c = li < p.n_splits ? min(p.list_counts[(uint64_t)q * p.n_splits + li], p.kprime) : 0u;
+        const uint32_t c = (lane < group && li < n_lists) ? min(p.list_counts[first + li], p.kprime) : 0u;
         uint32_t incl = c;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
             if (lane >= (uint32_t)off) incl += t;
         }
+        const uint32_t gtotal = (uint32_t)__shfl((int)incl, 63);
+        if (total + gtotal > MERGE_KEYS) {  // wave-uniform; then total > kprime, because gtotal <= MERGE_KEYS - kprime
+            __syncthreads();
+            const uint64_t kth = wave_kth_largest_lds(mkeys, total, p.kprime, lane);
+            uint32_t base = 0;
+            for (uint32_t i = 0; i < total; i += 64) {  // in-place: a chunk is read whole before any of its slots is written
+                const uint64_t key = (i + lane < total) ? mkeys[i + lane] : 0ull;
+                const bool keep = (i + lane < total) && key >= kth;
+                const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+                __syncthreads();
+                if (keep) mkeys[base + __builtin_popcountll(m & lt_mask)] = key;
+                base += __builtin_popcountll(m);
+                __syncthreads();
+            }
+            total = base;  // == kprime
+        }
         const uint32_t dst = total + incl - c;
-        const uint2* l = p.lists + ((uint64_t)q * p.n_splits + li) * p.cap;
+        const uint2* l = p.lists + (first + li) * p.cap;
         for (uint32_t i = 0; i < c; ++i) {
             const uint2 v = l[i];
             mkeys[dst + i] = cand_key(v.x, v.y);
         }
-        total += (uint32_t)__shfl((int)incl, 63);
+        total += gtotal;
     }
     __syncthreads();
     uint64_t prefix = 0;
     float tau = -INFINITY;
     if (total >= p.kprime) {
-        for (int bit = 63; bit >= 0; --bit) {
-            const uint64_t trial = prefix | (1ull << bit);
-            uint32_t cnt = 0;
-            for (uint32_t i = 0; i < total; i += 64) {
-                const bool ge = (i + lane < total) && (mkeys[i + lane] >= trial);
-                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ge));
-            }
-            if (cnt >= p.kprime) prefix = trial;
-        }
+        prefix = wave_kth_largest_lds(mkeys, total, p.kprime, lane);
         tau = ord2f((uint32_t)(prefix >> 32));
     }
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint32_t base = 0;
     for (uint32_t i = 0; i < total; i += 64) {
         const bool keep = (i + lane < total) && (mkeys[i + lane] >= prefix);
@@ -80,8 +111,77 @@ __global__ __launch_bounds__(64) void merge_select_kernel(PostParams p) {
 
 hipError_t launch_merge_select(const PostParams& p, hipStream_t stream) {
     if (p.q == 0) return hipSuccess;
-    const size_t lds = (size_t)p.n_splits * p.kprime * sizeof(uint64_t);
-    hipLaunchKernelGGL(merge_select_kernel, dim3(p.q), dim3(64), lds, stream, p);
+    if (p.kprime == 0 || p.kprime > (uint32_t)KPRIME_MAX) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(merge_select_kernel, dim3(p.q), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// dense_select: one wave per query over a row of the dense score matrix.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void dense_select_kernel(PostParams p) {
+    __shared__ uint32_t ord[DENSE_MAX_ROWS];
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    const float* sc = p.dense_scores + (uint64_t)q * p.dense_ld;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint32_t live = 0;
+    for (uint32_t i = 0; i < p.n; i += 64) {
+        const uint32_t r = i + lane;
+        bool ok = r < p.n;
+        if (ok && p.valid) ok = bit_set(p.valid, r);
+        if (ok && p.filter) ok = bit_set(p.filter, r);
+        if (r < p.n) ord[r] = ok ? f2ord(sc[r]) : 0u;  // 0 sorts below every real score (f2ord(-inf) = 0x007fffff)
+        live += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok));
+    }
+    __syncthreads();
+    uint32_t kth = 0, need_ties = 0xffffffffu;
+    float tau = -INFINITY;
+    if (live > p.kprime) {
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t trial = kth | (1u << bit);
+            uint32_t cnt = 0;
+            for (uint32_t i = 0; i < p.n; i += 64) {
+                const bool ge = (i + lane < p.n) && (ord[i + lane] >= trial);
+                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ge));
+            }
+            if (cnt >= p.kprime) kth = trial;
+        }
+        uint32_t gt = 0;
+        for (uint32_t i = 0; i < p.n; i += 64) {
+            const bool g = (i + lane < p.n) && (ord[i + lane] > kth);
+            gt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(g));
+        }
+        need_ties = p.kprime - gt;  // rows scoring exactly the kprime-th score: the lowest ids win
+        tau = ord2f(kth);
+    } else {
+        kth = 1;  // every live row (ord >= 0x007fffff) is a candidate
+    }
+    uint32_t base = 0, ties = 0;
+    for (uint32_t i = 0; i < p.n; i += 64) {
+        const uint32_t r = i + lane;
+        const uint32_t o = r < p.n ? ord[r] : 0u;
+        const bool tie = (live > p.kprime) && o == kth;
+        const uint64_t tm = __builtin_amdgcn_ballot_w64(tie);
+        const bool keep = (live > p.kprime) ? (o > kth || (tie && ties + __builtin_popcountll(tm & lt_mask) < need_ties)) : (o >= kth);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) {
+            const uint64_t slot = (uint64_t)q * p.kprime + base + __builtin_popcountll(m & lt_mask);
+            p.cand_ids[slot] = r;
+            if (p.cand_scores) p.cand_scores[slot] = ord2f(o);
+        }
+        base += __builtin_popcountll(m);
+        ties += __builtin_popcountll(tm);
+    }
+    if (lane == 0) {
+        p.cand_n[q] = base;
+        p.tau_star[q] = tau;
+    }
+}
+
+hipError_t launch_dense_select(const PostParams& p, hipStream_t stream) {
+    if (p.q == 0) return hipSuccess;
+    if (p.n > DENSE_MAX_ROWS || !p.dense_scores || p.kprime == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(dense_select_kernel, dim3(p.q), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 

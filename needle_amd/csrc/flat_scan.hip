@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
         if (q_live) {
             const uint2 e = iq[jq];
             my_query = e.x;
-            list_idx = e.x * p.nprobe + e.y;
+            list_idx = e.y;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -257,14 +257,17 @@ __device__ inline double band_eps(const TauBand& band, uint32_t q) {
 // the kseed-th largest listed score is a threshold that kseed live rows reach; the next launch starts from it.
 __global__ __launch_bounds__(64) void tau_refresh_kernel(const uint2* __restrict__ lists, const uint32_t* __restrict__ counts,
                                                          uint32_t n_lists, uint32_t cap, uint32_t kprime, uint32_t kseed,
-                                                         float* __restrict__ tau, TauBand band) {
+                                                         float* __restrict__ tau, TauBand band,
+                                                         const uint32_t* __restrict__ list_base) {
     constexpr uint32_t MAXE = 1024;  // more listed than this: keep the threshold (the lists are long anyway)
     __shared__ uint32_t ord[MAXE];
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    const uint64_t first = list_base ? list_base[q] : (uint64_t)q * n_lists;
+    if (list_base) n_lists = list_base[q + 1] - list_base[q];
     uint32_t total = 0;
     for (uint32_t l0 = 0; l0 < n_lists; l0 += 64) {
         const uint32_t li = l0 + lane;
-        const uint32_t c = li < n_lists ? min(counts[(uint64_t)q * n_lists + li], kprime) : 0u;
+        const uint32_t c = li < n_lists ? min(counts[first + li], kprime) : 0u;
         uint32_t incl = c;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(64) void tau_refresh_kernel(const uint2* __restrict
             if (lane >= (uint32_t)off) incl += t;
         }
         const uint32_t dst = total + incl - c;
-        const uint2* l = lists + ((uint64_t)q * n_lists + li) * cap;
+        const uint2* l = lists + (first + li) * cap;
         for (uint32_t i = 0; i < c; ++i)
             if (dst + i < MAXE) ord[dst + i] = f2ord(__uint_as_float(l[i].x));
         total += (uint32_t)__shfl((int)incl, 63);
@@ -298,10 +301,11 @@ __global__ __launch_bounds__(64) void tau_refresh_kernel(const uint2* __restrict
     }
 }
 
-hipError_t launch_tau_refresh(const ScanParams& p, uint32_t n_lists, float* d_tau, const TauBand& band, hipStream_t stream) {
+hipError_t launch_tau_refresh(const ScanParams& p, uint32_t n_lists, float* d_tau, const TauBand& band, hipStream_t stream,
+                              const uint32_t* d_list_base) {
     if (p.n_queries == 0) return hipSuccess;
     hipLaunchKernelGGL(tau_refresh_kernel, dim3(p.n_queries), dim3(64), 0, stream, p.lists, p.list_counts, n_lists, p.cap,
-                       p.kprime, p.kseed, d_tau, band);
+                       p.kprime, p.kseed, d_tau, band, d_list_base);
     return hipGetLastError();
 }
 
@@ -366,6 +370,7 @@ hipError_t launch_flat_prepass(int precision, const ScanParams& p, float* d_tau0
 
 hipError_t launch_ivf_scan(int precision, const ScanParams& p, uint32_t n_items, hipStream_t stream) {
     if (n_items == 0) return hipSuccess;
+    if (precision == NEEDLE_PRECISION_BF16) return launch_ivf_scan_bf16(p, n_items, stream);
     if (precision != NEEDLE_PRECISION_FP32) return hipErrorInvalidValue;
     hipLaunchKernelGGL(flat_scan_f32_kernel<MODE_IVF>, dim3(n_items), dim3(256), 0, stream, p);
     return hipGetLastError();

@@ -122,39 +122,65 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
     const uint32_t l31 = lane & 31, h = lane >> 5;
     constexpr uint32_t QB = 128 * NT;
 
-    uint32_t split, q_tile;
-    if (p.xcd_map) {
-        const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        split = xcd + 8 * (j / p.q_tiles);
-        q_tile = j % p.q_tiles;
-    } else {
-        split = blockIdx.x / p.q_tiles;
-        q_tile = blockIdx.x % p.q_tiles;
-    }
-    const uint32_t q0 = q_tile * QB + wave * (32 * NT);  // first query of this wave
-    // the block's run: tiles split + (jb + jj * jstep) * n_splits, jj = 0 .. cnt-1
-    const uint32_t own = split < p.n_tiles ? (p.n_tiles - split + p.n_splits - 1) / p.n_splits : 0u;  // tiles of this slice
-    uint32_t jb = 0, jstep = 1, cnt_tiles;
-    if (MODE == MODE_PRE) {
-        jstep = max(p.pre_stride, 1u);
-        cnt_tiles = min(p.pre_tiles, (own + jstep - 1) / jstep);
-    } else {
-        jb = min(p.tile_off, own);
-        cnt_tiles = min(p.tile_len, own - jb);
-    }
-    const uint32_t tile_mul = jstep * p.n_splits, tile_first = split + jb * p.n_splits;
-    const uint32_t t0 = 0, t1 = cnt_tiles;  // positions jj of the run
+    // FLAT / PRE: workgroup = (query block, slice); IVF: workgroup = one work item = a run of consecutive tiles of
+    // one inverted list x up to 128*NT of the (query, candidate list) pairs probing it.
+    uint32_t split = 0, q0 = 0, tile_first, tile_mul, cnt_tiles;
+    uint32_t my_query[NT];   // row of query_op each of this lane's columns multiplies
+    bool q_live[NT];
     float tau[NT];
     uint32_t cnt[NT], list_idx[NT];
     float gmax[NT][4];
+    if (MODE == MODE_IVF) {
+        const IvfItem it = p.items[blockIdx.x];
+        tile_first = it.tile0;
+        tile_mul = 1;
+        cnt_tiles = it.tile1 - it.tile0;
+        const uint2* iq = p.item_queries + it.qoff;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const uint32_t jq = wave * (32 * NT) + nt * 32 + l31;
+            q_live[nt] = jq < it.nq;
+            const uint2 e = q_live[nt] ? iq[jq] : make_uint2(0u, 0u);
+            my_query[nt] = e.x;
+            list_idx[nt] = e.y * 2 + h;  // every lane half owns a list
+        }
+    } else {
+        uint32_t q_tile;
+        if (p.xcd_map) {
+            const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+            split = xcd + 8 * (j / p.q_tiles);
+            q_tile = j % p.q_tiles;
+        } else {
+            split = blockIdx.x / p.q_tiles;
+            q_tile = blockIdx.x % p.q_tiles;
+        }
+        q0 = q_tile * QB + wave * (32 * NT);  // first query of this wave
+        // the block's run: tiles split + (jb + jj * jstep) * n_splits, jj = 0 .. cnt-1
+        const uint32_t own = split < p.n_tiles ? (p.n_tiles - split + p.n_splits - 1) / p.n_splits : 0u;  // tiles of this slice
+        uint32_t jb = 0, jstep = 1;
+        if (MODE == MODE_PRE) {
+            jstep = max(p.pre_stride, 1u);
+            cnt_tiles = min(p.pre_tiles, (own + jstep - 1) / jstep);
+        } else {
+            jb = min(p.tile_off, own);
+            cnt_tiles = min(p.tile_len, own - jb);
+        }
+        tile_mul = jstep * p.n_splits;
+        tile_first = split + jb * p.n_splits;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            my_query[nt] = q0 + nt * 32 + l31;
+            q_live[nt] = my_query[nt] < p.n_queries;
+            list_idx[nt] = (my_query[nt] * p.n_splits + split) * 2 + h;
+        }
+    }
+    const uint32_t t0 = 0, t1 = cnt_tiles;  // positions jj of the run
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const uint32_t my_query = q0 + nt * 32 + l31;
-        list_idx[nt] = (my_query * p.n_splits + split) * 2 + h;
         tau[nt] = -INFINITY;
-        if (MODE != MODE_PRE && p.tau0) tau[nt] = p.tau0[my_query];
-        if ((p.debug & 1u) || my_query >= p.n_queries) tau[nt] = INFINITY;
-        cnt[nt] = (MODE != MODE_PRE && p.resume) ? p.list_counts[list_idx[nt]] : 0u;
+        if (MODE != MODE_PRE && p.tau0 && q_live[nt]) tau[nt] = p.tau0[my_query[nt]];
+        if ((p.debug & 1u) || !q_live[nt]) tau[nt] = INFINITY;
+        cnt[nt] = (MODE == MODE_FLAT && p.resume) ? p.list_counts[list_idx[nt]] : 0u;
 #pragma unroll
         for (int g = 0; g < 4; ++g) gmax[nt][g] = -INFINITY;
     }
@@ -169,7 +195,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
         const uint16_t* __restrict__ gB = (const uint16_t*)p.query_op;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const uint16_t* qrow = gB + (uint64_t)(q0 + nt * 32 + l31) * p.dpad + 8 * h;
+            const uint16_t* qrow = gB + (uint64_t)my_query[nt] * p.dpad + 8 * h;  // (a dead IVF slot reads query 0: never lists)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) bq[nt][ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(qrow + ks * 16));
         }
@@ -315,6 +341,17 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
                                 if (!plain) ok = row_live<MODE_FLAT>(p, row0 + mt * 32 + row_of_reg(r, h));
                                 if (ok) gmax[nt][half * 2 + mt] = fmaxf(gmax[nt][half * 2 + mt], acc[mt][nt][r]);
                             }
+                } else if (MODE == MODE_DENSE) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        float* dst = p.dense_scores + (uint64_t)my_query[nt] * p.dense_ld + row0 + 4 * h;
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)  // registers 4j .. 4j+3 = rows mt*32 + 8j + 4h .. + 3
+                                *(f32x4*)(dst + mt * 32 + 8 * j) = f32x4{acc[mt][nt][4 * j], acc[mt][nt][4 * j + 1],
+                                                                          acc[mt][nt][4 * j + 2], acc[mt][nt][4 * j + 3]};
+                    }
                 } else {
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
@@ -336,6 +373,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
     }
 #endif
 
+    if (MODE == MODE_DENSE) return;
     if (MODE == MODE_PRE) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -356,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
             wave_compact_list(p.lists + (uint64_t)li * p.cap, n_e, p.kprime, lane);
             if (lane == b) cnt[nt] = p.kprime;
         }
-        p.list_counts[list_idx[nt]] = cnt[nt];
+        if (MODE != MODE_IVF || q_live[nt]) p.list_counts[list_idx[nt]] = cnt[nt];
     }
 }
 
@@ -384,6 +422,46 @@ static hipError_t launch_bf16_mode(const ScanParams& p, hipStream_t stream) {
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+// inverted-list scan (Euclidean: the accumulators are always seeded): one workgroup per p.items[i]
+hipError_t launch_ivf_scan_bf16(const ScanParams& p, uint32_t n_items, hipStream_t stream) {
+    if (n_items == 0) return hipSuccess;
+    if (!p.cinit) return hipErrorInvalidValue;
+    const dim3 grid(n_items), block(256);
+    switch (p.dpad) {
+    case 128: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE_IVF, 2, 8, true>), grid, block, 0, stream, p); break;
+    case 256: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE_IVF, 2, 16, true>), grid, block, 0, stream, p); break;
+    case 384: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE_IVF, 2, 24, true>), grid, block, 0, stream, p); break;
+    case 512: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE_IVF, 1, 32, true>), grid, block, 0, stream, p); break;
+    case 768: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE_IVF, 1, 48, true>), grid, block, 0, stream, p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+template <bool CINIT>
+static hipError_t launch_bf16_dense(const ScanParams& p, hipStream_t stream) {
+    const dim3 grid(p.n_splits * p.q_tiles), block(256);
+    switch (p.dpad) {
+    case 128: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE_DENSE, 2, 8, CINIT>), grid, block, 0, stream, p); break;
+    case 256: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE_DENSE, 2, 16, CINIT>), grid, block, 0, stream, p); break;
+    case 384: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE_DENSE, 2, 24, CINIT>), grid, block, 0, stream, p); break;
+    case 512: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE_DENSE, 1, 32, CINIT>), grid, block, 0, stream, p); break;
+    case 768: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE_DENSE, 1, 48, CINIT>), grid, block, 0, stream, p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// every score of [q_pad] x [n_pad] written to p.dense_scores (row stride p.dense_ld >= n_pad)
+hipError_t launch_dense_scores_bf16(const ScanParams& p0, hipStream_t stream) {
+    if (p0.n_splits * p0.q_tiles == 0) return hipSuccess;
+    if (!p0.dense_scores) return hipErrorInvalidValue;
+    ScanParams p = p0;
+    p.tile_off = 0;
+    p.tile_len = p.tiles_per_split;
+    return p.cinit ? launch_bf16_dense<true>(p, stream) : launch_bf16_dense<false>(p, stream);
 }
 
 hipError_t launch_flat_scan_bf16(const ScanParams& p0, bool prepass, hipStream_t stream) {

@@ -107,7 +107,7 @@ struct needle_hip_index {
     nh::DevBuf w_qerr;  // [q_pad] |query operand - its bf16 copy|
     nh::DevBuf r_idx, r_q, r_ids, r_dists, r_cnt;  // queries a reduced-precision pass could not decide, re-run in fp32
     nh::DevBuf x_keys, x_u32, x_u64, x_sel, x_mask;
-    nh::DevBuf v_probe_ids, v_probe_d, v_probe_n, v_probe32, v_items, v_itemq;
+    nh::DevBuf v_probe_ids, v_probe_d, v_probe_n, v_probe32, v_items, v_itemq, v_lbase;
 };
 
 namespace nh {
@@ -121,6 +121,8 @@ needle_hip_status run_exact(needle_hip_index* ix, const float* d_queries, const 
                             uint32_t* d_out_counts, const uint32_t* d_probe = nullptr,
                             const uint32_t* d_probe_n = nullptr, uint32_t nprobe = 0);
 uint32_t choose_kprime(uint32_t k, int precision);
+// builds ix->d_op_bf16 (and ix->bf16_err) on first use; the caller holds ix->mu
+needle_hip_status ensure_bf16_copy(needle_hip_index* ix);
 needle_hip_index* index_new();  // registered as live; null when out of host memory
 void index_free(needle_hip_index* ix);
 needle_hip_status finish_operands(needle_hip_index* ix, bool validate);

@@ -128,12 +128,15 @@ struct ScanParams {
     // a launch may cover only tiles [tile_off, tile_off + tile_len) of every slice; `resume` continues the
     // candidate lists of the launch before it (counts are read back), with thresholds refreshed in between
     uint32_t tile_off, tile_len, resume;
+    // small bases: the scan writes every score to dense_scores[query][dense_ld] (row-major per query) and a
+    // selection kernel takes the candidates from there; no lists
+    float* dense_scores;
+    uint32_t dense_ld;
     // inverted-list scan: one workgroup per work item = (one list's row tiles) x (<= 128 of the
     // queries probing that list); rows are positions in the list-ordered copy of the base
     const IvfItem* items;     // [grid]
-    const uint2* item_queries;  // (query index, probe slot) per item entry
+    const uint2* item_queries;  // (query index, index of the candidate list this entry fills) per item entry
     const uint32_t* pos2id;   // [n_pad] original row id of a position, ~0 for padding
-    uint32_t nprobe;          // candidate list of (query, slot) is lists[(query * nprobe + slot) * cap]
     uint32_t base_is_u8;      // base_op is a u8 code matrix (scalar-quantized scan)
 };
 

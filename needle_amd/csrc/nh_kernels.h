@@ -21,7 +21,9 @@ struct TauBand {
 hipError_t launch_flat_prepass(int precision, const ScanParams& p, float* d_tau0, const TauBand& band, hipStream_t stream);
 // between two launches sharing lists: d_tau[q] = max(d_tau[q], kseed-th largest score listed for q so far
 // minus twice the score uncertainty)
-hipError_t launch_tau_refresh(const ScanParams& p, uint32_t n_lists, float* d_tau, const TauBand& band, hipStream_t stream);
+// (d_list_base as in PostParams::list_base, with n_lists = the largest number of lists any query owns)
+hipError_t launch_tau_refresh(const ScanParams& p, uint32_t n_lists, float* d_tau, const TauBand& band, hipStream_t stream,
+                              const uint32_t* d_list_base = nullptr);
 // inverted-list scan: one workgroup per p.items[i]
 hipError_t launch_ivf_scan(int precision, const ScanParams& p, uint32_t n_items, hipStream_t stream);
 int flat_scan_blocks_per_cu(int precision);
@@ -36,6 +38,9 @@ uint32_t flat_scan_bf16_dpad(uint32_t dim);
 uint32_t flat_scan_bf16_queries_per_block(uint32_t dpad);
 // Candidate lists are per (query, slice, lane half): 2 * n_splits lists per query.
 hipError_t launch_flat_scan_bf16(const ScanParams& p, bool prepass, hipStream_t stream);
+// inverted-list scan: items hold up to flat_scan_bf16_queries_per_block(dpad) entries; entry .y names a PAIR of
+// candidate lists (2 * y and 2 * y + 1, one per lane half)
+hipError_t launch_ivf_scan_bf16(const ScanParams& p, uint32_t n_items, hipStream_t stream);
 
 // ---- prep.hip --------------------------------------------------------------
 // Per row: |b|, |b|^2 (wave-parallel sums; used by the first pass and its error
@@ -74,12 +79,17 @@ struct PostParams {
     double berr;              // bf16 operands: max |row operand - its bf16 copy|; SQ8: max |code vector|
     const uint2* lists;
     const uint32_t* list_counts;
+    const uint32_t* list_base; // [q + 1] or null: query q owns lists list_base[q] .. list_base[q+1]-1 (else q*n_splits ..)
     uint32_t* cand_ids;       // [q][kprime]
     uint32_t* cand_n;         // [q]
     float* cand_scores;       // [q][kprime] first-pass scores of the kept candidates, or null
     float* tau_star;          // [q]
     const float* tau0;        // [q] threshold the main pass started from, or null
     const uint32_t* pos2id;   // candidates are positions of a list-ordered copy: their row ids, or null
+    const float* dense_scores;  // dense path: [q][dense_ld] first-pass scores, with the masks the scan would apply
+    uint32_t dense_ld;
+    const uint32_t* valid;
+    const uint32_t* filter;
     // scalar-quantized rows: distances are ScalarQuantizer::asymmetric_distance on the codes
     const uint8_t* sq_codes;  // [n_pad][sq_stride] or null
     const float* sq_min;      // [dim]
@@ -96,6 +106,11 @@ struct PostParams {
     float max_norm;
 };
 hipError_t launch_merge_select(const PostParams& p, hipStream_t stream);
+// Small bases: candidates straight from the dense score matrix p.dense_scores[q][dense_ld] (the kprime best live
+// rows by (score, lower id); tau* = the kprime-th score, -inf when every live row is a candidate).  n <= DENSE_MAX_ROWS.
+constexpr uint32_t DENSE_MAX_ROWS = 8192;
+hipError_t launch_dense_select(const PostParams& p, hipStream_t stream);
+hipError_t launch_dense_scores_bf16(const ScanParams& p, hipStream_t stream);
 hipError_t launch_rescore_finalize(const PostParams& p, hipStream_t stream);
 // For scans whose scores ARE the reference distances (score = -distance): rank the merged
 // candidates by (distance, id) and emit the k best.  Needs cand_scores.

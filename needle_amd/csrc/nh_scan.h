@@ -8,7 +8,7 @@ namespace nh {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum ScanMode { MODE_FLAT = 0, MODE_PRE = 1, MODE_IVF = 2 };
+enum ScanMode { MODE_FLAT = 0, MODE_PRE = 1, MODE_IVF = 2, MODE_DENSE = 3 };  // DENSE: every score is written out
 
 // accumulator register r of lane half h holds result row (r&3) + 8*(r>>2) + 4*h
 __device__ inline uint32_t row_of_reg(int r, uint32_t h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }

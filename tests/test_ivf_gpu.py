@@ -57,6 +57,28 @@ def test_assignment_probe_and_search(ctx, oracle, shape):
     for i in range(queries.shape[0]):
         assert np.array_equal(probes[i], oracle.ivf_probe(queries[i], cents, nprobe)), i
     _check_search(oracle, ix, base, cents, offsets, order, queries, nprobe, k)
+    _check_search(oracle, ix, base, cents, offsets, order, queries, nprobe, k, precision="bf16")  # bf16 list scan, same hits
+    ix.close()
+
+
+def test_hub_lists_are_cut_into_runs(ctx, oracle):
+    """Gaussian rows around randomly drawn centroids: a few lists hold most rows and span many tile runs."""
+    from needle_amd.ivf import IvfConfig, IvfIndex
+
+    rng = np.random.default_rng(12)
+    n, d, nlist, nprobe = 60000, 48, 24, 6
+    base = rng.standard_normal((n, d)).astype(F)
+    cents = np.ascontiguousarray(base[rng.choice(n, nlist, replace=False)] * F(3.0))
+    cents[:3] = base[:3] * F(0.1)  # three centroids near the origin attract almost everything
+    ix = IvfIndex(d, IvfConfig.new(nlist).with_nprobe(nprobe), ctx=ctx)
+    ix.set_centroids(cents)
+    ix.add(range(n), base)
+    assign = oracle.ivf_assign(base, cents)
+    offsets, order = oracle.ivf_lists_from_assignment(assign, nlist)
+    assert np.diff(offsets).max() > 8 * 1024  # several runs of 8 tiles
+    queries = rng.standard_normal((300, d)).astype(F)
+    for precision in ("fp32", "bf16"):
+        _check_search(oracle, ix, base, cents, offsets, order, queries, nprobe, 10, precision=precision)
     ix.close()
 
 

@@ -117,7 +117,8 @@ def ivf_case(ctx, dev, n, dim, nlist, nprobe, nq, k, steps, oracle=None):
                                                C.byref(h)))
     build_s = time.perf_counter() - t0
     dq = torch.from_numpy(queries).to(dev)
-    sec, out = timed(lambda: search_device(h, dq, k, nprobe=nprobe), steps, 1)
+    sec32, _ = timed(lambda: search_device(h, dq, k, nprobe=nprobe, precision="fp32"), steps, 1)
+    sec, out = timed(lambda: search_device(h, dq, k, nprobe=nprobe, precision="bf16"), steps, 1)
     sizes = np.zeros(nlist, dtype=np.uint32)
     _lib.check(_lib.lib().needle_hip_ivf_list_sizes(h, sizes.ctypes.data))
     probe = np.full((nq, nprobe), 0xFFFFFFFF, dtype=np.uint32)
@@ -130,7 +131,8 @@ def ivf_case(ctx, dev, n, dim, nlist, nprobe, nq, k, steps, oracle=None):
     bytes_once = int(padded[per_list > 0].sum()) * row_bytes                         # every probed list once
     bytes_unbatched = int((per_list * sizes.astype(np.int64)).sum()) * row_bytes     # per-query scans, as the reference
     pairs = int((per_list * sizes.astype(np.int64)).sum())
-    extra = {"build_s": round(build_s, 2), "scanned_pairs": pairs,
+    extra = {"list_scan": "bf16", "fp32_list_scan_ms_per_batch": round(sec32 * 1e3, 3), "build_s": round(build_s, 2),
+             "scanned_pairs": pairs,
              "bytes_listmajor": bytes_items, "bytes_each_probed_list_once": bytes_once, "bytes_unbatched": bytes_unbatched,
              "listmajor_GBps_over_whole_search": round(bytes_items / sec / 1e9, 1),
              "frac_of_hbm_peak": round(bytes_items / sec / 1e9 / HBM_PEAK_GBS, 4),
