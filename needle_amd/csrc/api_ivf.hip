@@ -44,7 +44,7 @@ __global__ void ivf_narrow_probe_kernel(const uint64_t* __restrict__ ids, uint32
 // query's nearest list with plain vector arithmetic, in the first pass's score units (q.b - |b|^2/2), and takes
 // the kseed-th largest score of live rows minus twice the score uncertainty: kseed live rows reach it, so the
 // scan may start from it (a lower rank or a shorter sample only makes the threshold weaker, never wrong).
-constexpr uint32_t IVF_SEED_ROWS = 512;
+constexpr uint32_t IVF_SEED_ROWS = 256;
 
 __global__ __launch_bounds__(64) void ivf_seed_tau_kernel(const float* __restrict__ queries, const float* __restrict__ rows,
                                                           const float* __restrict__ cinit, const uint32_t* __restrict__ probe,
@@ -62,18 +62,28 @@ __global__ __launch_bounds__(64) void ivf_seed_tau_kernel(const float* __restric
         const uint32_t p0 = list_pos[l], len = min(list_len[l], IVF_SEED_ROWS);
         const float* qv = queries + (uint64_t)q * dim;
         uint32_t live = 0;
-        for (uint32_t r = 0; r < len; ++r) {
-            const float* b = rows + (uint64_t)(p0 + r) * dim;
-            float s = 0.0f;
-            for (uint32_t i = lane; i < dim; i += 64) s += qv[i] * b[i];
-            for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
-            const uint32_t id = pos2id[p0 + r];
-            bool ok = id != 0xffffffffu;
-            if (ok && valid) ok = nh::bit_set(valid, id);
-            if (ok && filter) ok = nh::bit_set(filter, id);
-            if (ok) {  // wave-uniform
-                if (lane == 0) ord[live] = nh::f2ord(s + cinit[p0 + r]);
-                live += 1;
+        for (uint32_t r0 = 0; r0 < len; r0 += 4) {  // four rows per step: independent loads and reductions
+            float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (uint32_t i = lane; i < dim; i += 64) {
+                const float x = qv[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] += x * rows[(uint64_t)(p0 + min(r0 + j, len - 1)) * dim + i];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                for (int off = 32; off; off >>= 1) s[j] += __shfl_xor(s[j], off);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t r = r0 + j;
+                if (r >= len) break;
+                const uint32_t id = pos2id[p0 + r];
+                bool ok = id != 0xffffffffu;
+                if (ok && valid) ok = nh::bit_set(valid, id);
+                if (ok && filter) ok = nh::bit_set(filter, id);
+                if (ok) {  // wave-uniform
+                    if (lane == 0) ord[live] = nh::f2ord(s[j] + cinit[p0 + r]);
+                    live += 1;
+                }
             }
         }
         __syncthreads();

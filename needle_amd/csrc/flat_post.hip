@@ -23,7 +23,8 @@ namespace nh {
 // group would not fit, what has been gathered so far is first cut down to its kprime best (the cut only ever
 // removes keys below the final kprime-th one).
 // ---------------------------------------------------------------------------
-constexpr uint32_t MERGE_KEYS = 4096 + KPRIME_MAX;
+constexpr uint32_t MERGE_KEYS = 2048 + KPRIME_MAX;
+constexpr uint32_t MERGE_FAST_LISTS = 1024;  // lists per query the one-shot gather handles
 
 // kprime-th largest of keys[0 .. total) (total >= kprime), found bit by bit; all keys are distinct
 __device__ inline uint64_t wave_kth_largest_lds(const uint64_t* keys, uint32_t total, uint32_t kprime, uint32_t lane) {
@@ -46,10 +47,44 @@ __global__ __launch_bounds__(64) void merge_select_kernel(PostParams p) {
     const uint64_t first = p.list_base ? p.list_base[q] : (uint64_t)q * p.n_splits;
     const uint32_t n_lists = p.list_base ? p.list_base[q + 1] - p.list_base[q] : p.n_splits;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    __shared__ uint32_t loff[MERGE_FAST_LISTS + 1];
+    uint32_t total = 0;
+    bool done = false;
+    if (n_lists <= MERGE_FAST_LISTS) {
+        // common case: all counts at once (independent loads), then every lane copies entries lane, lane+64, ... of
+        // the concatenation, finding the list of an entry by bisection of the offsets
+        for (uint32_t l0 = 0; l0 < n_lists; l0 += 64) {
+            const uint32_t li = l0 + lane;
+            const uint32_t c = li < n_lists ? min(p.list_counts[first + li], p.kprime) : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
+                if (lane >= (uint32_t)off) incl += t;
+            }
+            if (li < n_lists) loff[li] = total + incl - c;
+            total += (uint32_t)__shfl((int)incl, 63);
+        }
+        if (lane == 0) loff[n_lists] = total;
+        __syncthreads();
+        if (total <= MERGE_KEYS) {
+            for (uint32_t e = lane; e < total; e += 64) {
+                uint32_t lo = 0, hi = n_lists;  // largest list index with loff <= e
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (loff[mid] <= e) lo = mid; else hi = mid;
+                }
+                const uint2 v = p.lists[(first + lo) * p.cap + (e - loff[lo])];
+                mkeys[e] = cand_key(v.x, v.y);
+            }
+            done = true;
+        } else {
+            total = 0;
+        }
+    }
     // lists per group: their entries (<= kprime each) fit beside kprime kept keys
     const uint32_t group = min(64u, max(1u, (MERGE_KEYS - p.kprime) / p.kprime));
-    uint32_t total = 0;
-    for (uint32_t l0 = 0; l0 < n_lists; l0 += group) {
+    for (uint32_t l0 = 0; !done && l0 < n_lists; l0 += group) {
         // lane l copies list l0 + l: the lists are short, so the copies run side by side
         const uint32_t li = l0 + lane;
         const uint32_t c = (lane < group && li < n_lists) ? min(p.list_counts[first + li], p.kprime) : 0u;
@@ -120,8 +155,9 @@ hipError_t launch_merge_select(const PostParams& p, hipStream_t stream) {
 // dense_select: one wave per query over a row of the dense score matrix.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void dense_select_kernel(PostParams p) {
-    __shared__ uint32_t ord[DENSE_MAX_ROWS];
+    extern __shared__ uint32_t ord[];  // [round_up(n, 256)], the tail holds 0
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    const uint32_t n4 = (p.n + 255u) & ~255u;
     const float* sc = p.dense_scores + (uint64_t)q * p.dense_ld;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint32_t live = 0;
@@ -133,6 +169,7 @@ __global__ __launch_bounds__(64) void dense_select_kernel(PostParams p) {
         if (r < p.n) ord[r] = ok ? f2ord(sc[r]) : 0u;  // 0 sorts below every real score (f2ord(-inf) = 0x007fffff)
         live += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok));
     }
+    for (uint32_t r = p.n + lane; r < n4; r += 64) ord[r] = 0u;
     __syncthreads();
     uint32_t kth = 0, need_ties = 0xffffffffu;
     float tau = -INFINITY;
@@ -140,9 +177,12 @@ __global__ __launch_bounds__(64) void dense_select_kernel(PostParams p) {
         for (int bit = 31; bit >= 0; --bit) {
             const uint32_t trial = kth | (1u << bit);
             uint32_t cnt = 0;
-            for (uint32_t i = 0; i < p.n; i += 64) {
-                const bool ge = (i + lane < p.n) && (ord[i + lane] >= trial);
-                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ge));
+            for (uint32_t i = 0; i < n4; i += 256) {  // four independent reads per step (trial > 0 excludes the tail)
+                const uint32_t o0 = ord[i + lane], o1 = ord[i + 64 + lane], o2 = ord[i + 128 + lane], o3 = ord[i + 192 + lane];
+                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(o0 >= trial)) +
+                       __builtin_popcountll(__builtin_amdgcn_ballot_w64(o1 >= trial)) +
+                       __builtin_popcountll(__builtin_amdgcn_ballot_w64(o2 >= trial)) +
+                       __builtin_popcountll(__builtin_amdgcn_ballot_w64(o3 >= trial));
             }
             if (cnt >= p.kprime) kth = trial;
         }
@@ -181,7 +221,8 @@ __global__ __launch_bounds__(64) void dense_select_kernel(PostParams p) {
 hipError_t launch_dense_select(const PostParams& p, hipStream_t stream) {
     if (p.q == 0) return hipSuccess;
     if (p.n > DENSE_MAX_ROWS || !p.dense_scores || p.kprime == 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(dense_select_kernel, dim3(p.q), dim3(64), 0, stream, p);
+    const size_t lds = (size_t)((p.n + 255u) & ~255u) * sizeof(uint32_t);
+    hipLaunchKernelGGL(dense_select_kernel, dim3(p.q), dim3(64), lds, stream, p);
     return hipGetLastError();
 }
 
