@@ -475,10 +475,18 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     uint32_t n_flagged = 0;
     HIP_TRY(hipMemcpyAsync(&n_flagged, pp.flag_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    double dbg_listed = -1.0;
+    if (dbg_t) {
+        std::vector<uint32_t> lc(total_lists);
+        HIP_TRY(hipMemcpy(lc.data(), ix->w_lcnt.p, (size_t)total_lists * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint64_t tot = 0;
+        for (uint32_t v : lc) tot += std::min(v, kprime);
+        dbg_listed = (double)tot / q;
+    }
     if (dbg_t)
         fprintf(stderr, "[needle_hip] ivf: %u queries, %zu items, %u candidate lists (busiest query %u, run %u tiles); probe %.2f ms, "
-                "host regroup %.2f ms, device scan+post %.2f ms, undecided %u\n", q, items.size(), total_lists, busiest, run,
-                t_probe_done - t_entry, t_items_done - t_probe_done, now() - t_items_done, n_flagged);
+                "host regroup %.2f ms, device scan+post %.2f ms, undecided %u, listed %.1f per query\n", q, items.size(), total_lists,
+                busiest, run, t_probe_done - t_entry, t_items_done - t_probe_done, now() - t_items_done, n_flagged, dbg_listed);
     if (c->profiling) {
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
