@@ -683,10 +683,12 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     }
     if (n_flagged > 0) {
         if (n_flagged > q) n_flagged = q;
-        if (bf16 && n_flagged > 16) {
+        // The exact scan streams the base once per 4 queries: cheaper than another first pass for a handful of
+        // queries, or for any number of them over a small base (an IVF centroid set).
+        const bool few = n_flagged <= 16 || (uint64_t)n_flagged * ix->n_pad <= (4ull << 20);
+        if (bf16 && !few) {
             // The bf16 scores could not separate these queries' k-th hit from the rows left out: give them
             // the fp32 first pass (whose own leftovers go to the exact scan) and put the answers in place.
-            // (A handful of queries is cheaper on the exact scan, which streams the base once per 4 of them.)
             HIP_TRY(ix->r_idx.ensure((size_t)n_flagged * sizeof(uint32_t)));
             HIP_TRY(ix->r_q.ensure((size_t)n_flagged * ix->dim * sizeof(float)));
             HIP_TRY(ix->r_ids.ensure((size_t)n_flagged * k * sizeof(uint64_t)));

@@ -16,7 +16,9 @@
 //      check, exact scan of the probed lists for rejected queries (flat_post.hip)
 #include "nh_api.h"
 
+#include <algorithm>
 #include <chrono>
+#include <functional>
 
 using namespace nh;
 
@@ -107,6 +109,115 @@ __global__ __launch_bounds__(64) void ivf_seed_tau_kernel(const float* __restric
     if (lane == 0) tau[q] = t;
 }
 
+// ---- regrouping of the (query, probed list) pairs by list, on the device ----------------------------------
+// Stage r of the list scan covers probe slots [bounds[r], bounds[r+1]); per (stage, list) the pairs probing the list
+// are collected (counting sort: count, exclusive scan, scatter) and cut into work items of <= item_queries pairs per
+// run of `run` row tiles.  The order of the pairs inside a list follows the atomics and is not deterministic; the
+// answer does not depend on it (every pair owns its candidate lists, and the bound check proves the result).
+struct RegroupBufs {
+    const uint32_t *probe, *probe_n, *list_len, *list_pos;
+    uint32_t *cnt, *fill, *pair_off, *item_off;  // [3 * nlist] (+1 for the offsets)
+    uint32_t *qlists, *lbase, *lbase_dev;        // candidate lists of every query; exclusive sums ([q + 1]; x lpe)
+    uint32_t* slot_rel;                          // [q][np] first candidate list of (query, slot), relative to the query
+    uint32_t* totals;                            // [0] candidate lists, [1..3] end of stage 0..2 in items, [4] most lists of one query
+    uint2* itemq;
+    nh::IvfItem* items;
+    uint32_t q, np, nlist, run, item_queries, lpe, b1, b2;
+};
+
+__device__ __forceinline__ uint32_t rg_runs(const RegroupBufs& g, uint32_t l) {
+    const uint32_t tiles = (g.list_len[l] + nh::TILE_ROWS - 1) / nh::TILE_ROWS;
+    return max(1u, (tiles + g.run - 1) / g.run);
+}
+__device__ __forceinline__ uint32_t rg_stage(const RegroupBufs& g, uint32_t slot) { return slot < g.b1 ? 0u : slot < g.b2 ? 1u : 2u; }
+
+__global__ __launch_bounds__(256) void ivf_regroup_count_kernel(RegroupBufs g) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.q) return;
+    uint32_t at = 0;
+    const uint32_t n = min(g.probe_n[i], g.np);
+    for (uint32_t sl = 0; sl < n; ++sl) {
+        const uint32_t l = g.probe[(uint64_t)i * g.np + sl];
+        g.slot_rel[(uint64_t)i * g.np + sl] = at;
+        at += rg_runs(g, l);
+        atomicAdd(&g.cnt[rg_stage(g, sl) * g.nlist + l], 1u);
+    }
+    g.qlists[i] = at;
+}
+
+// exclusive sums of value(0 .. n-1) into out[0 .. n] by one workgroup of 1024 threads; returns the total
+template <typename F>
+__device__ uint32_t rg_block_scan(uint32_t n, F value, uint32_t* out, uint32_t* part) {
+    const uint32_t t = threadIdx.x, per = (n + 1023) / 1024;
+    const uint32_t b = min(n, t * per), e = min(n, b + per);
+    uint32_t s = 0;
+    for (uint32_t i = b; i < e; ++i) s += value(i);
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t acc = t ? part[t - 1] : 0u;
+    const uint32_t total = part[1023];
+    for (uint32_t i = b; i < e; ++i) {
+        out[i] = acc;
+        acc += value(i);
+    }
+    if (t == 0) out[n] = total;
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(1024) void ivf_regroup_scan_kernel(RegroupBufs g) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t most;
+    if (threadIdx.x == 0) most = 0;
+    __syncthreads();
+    const uint32_t SL = 3 * g.nlist;
+    const uint32_t total_lists = rg_block_scan(g.q, [&](uint32_t i) { return g.qlists[i]; }, g.lbase, part);
+    for (uint32_t i = threadIdx.x; i <= g.q; i += 1024) g.lbase_dev[i] = g.lbase[i] * g.lpe;
+    uint32_t m = 0;
+    for (uint32_t i = threadIdx.x; i < g.q; i += 1024) m = max(m, g.qlists[i]);
+    atomicMax(&most, m);
+    rg_block_scan(SL, [&](uint32_t i) { return g.cnt[i]; }, g.pair_off, part);
+    rg_block_scan(SL, [&](uint32_t i) {
+        const uint32_t l = i % g.nlist, c = g.cnt[i];
+        return (c == 0 || g.list_len[l] == 0) ? 0u : rg_runs(g, l) * ((c + g.item_queries - 1) / g.item_queries);
+    }, g.item_off, part);
+    if (threadIdx.x == 0) {
+        g.totals[0] = total_lists;
+        g.totals[1] = g.item_off[g.nlist];
+        g.totals[2] = g.item_off[2 * g.nlist];
+        g.totals[3] = g.item_off[SL];
+        g.totals[4] = most;
+    }
+}
+
+__global__ __launch_bounds__(256) void ivf_regroup_scatter_kernel(RegroupBufs g) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.q * g.np) return;
+    const uint32_t i = t / g.np, sl = t % g.np;
+    if (sl >= min(g.probe_n[i], g.np)) return;
+    const uint32_t l = g.probe[t], e = rg_stage(g, sl) * g.nlist + l;
+    const uint32_t at = g.pair_off[e] + atomicAdd(&g.fill[e], 1u);
+    g.itemq[at] = make_uint2(i, g.lbase[i] + g.slot_rel[t]);
+}
+
+__global__ __launch_bounds__(256) void ivf_regroup_items_kernel(RegroupBufs g) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= 3 * g.nlist) return;
+    const uint32_t l = e % g.nlist, c = g.cnt[e], len = g.list_len[l];
+    if (c == 0 || len == 0) return;
+    const uint32_t t0 = g.list_pos[l] / nh::TILE_ROWS, nt = (len + nh::TILE_ROWS - 1) / nh::TILE_ROWS;
+    uint32_t at = g.item_off[e];
+    for (uint32_t ch = 0; ch * g.run < nt; ++ch)
+        for (uint32_t o = 0; o < c; o += g.item_queries)
+            g.items[at++] = nh::IvfItem{t0 + ch * g.run, t0 + min(nt, (ch + 1) * g.run), g.pair_off[e] + o, min(g.item_queries, c - o), ch};
+}
+
 extern "C" needle_hip_status needle_hip_ivf_build(needle_hip_ctx* c, const float* base, uint64_t n, uint32_t dim,
                                                   const float* centroids, uint32_t nlist, const uint32_t* assignment,
                                                   const uint32_t* valid_bitmask, needle_hip_index** out) {
@@ -151,6 +262,9 @@ extern "C" needle_hip_status needle_hip_ivf_build(needle_hip_ctx* c, const float
         ix->list_pos[l] = (uint32_t)pos;
         pos += round_up(ix->list_len[l], TILE_ROWS);
     }
+    ix->list_tiles_desc.resize(nlist);
+    for (uint32_t l = 0; l < nlist; ++l) ix->list_tiles_desc[l] = round_up(ix->list_len[l], TILE_ROWS) / TILE_ROWS;
+    std::sort(ix->list_tiles_desc.begin(), ix->list_tiles_desc.end(), std::greater<uint32_t>());
     if (pos >= 0xfffffff0ull) { index_free(ix); return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "padded IVF layout exceeds 2^32 positions"); }
     ix->n_pad = (uint32_t)pos;
     std::vector<uint32_t> pos2id((size_t)ix->n_pad, 0xffffffffu), fill(nlist, 0);
@@ -291,88 +405,64 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
         return NEEDLE_HIP_OK;
     }
 
-    // regroup (query, probed list) pairs by list on the host: q * np small integers
+    // Regroup the (query, probed list) pairs by list ON THE DEVICE (ivf_regroup_* kernels above); the host reads
+    // back five counters.
+    // Work items.  A list is cut into runs of at most `run` row tiles, so that a long list (hub centroid) becomes
+    // many workgroups instead of one long one; every (query, probed list, run) owns a candidate list of its own,
+    // numbered consecutively per query: query i owns lists list_base[i] .. list_base[i+1]-1.  `run` doubles until the
+    // lists of any query (bounded by the nprobe longest lists of the index) fit the merge kernel's bookkeeping.
+    // Thresholds start from a sample of every query's nearest list (ivf_seed_tau_kernel).  The probe slots are then
+    // scanned in up to three launches (by default slots 0-3, then the rest); after each launch a query's threshold
+    // is raised to the (k+6)-th best score it has listed, so the far lists only list what can still matter.
     const bool dbg_t = getenv("NEEDLE_HIP_DEBUG") && (atoi(getenv("NEEDLE_HIP_DEBUG")) & 8);
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     if (dbg_t) HIP_TRY(hipStreamSynchronize(c->stream));
     const double t_probe_done = now();
-    std::vector<uint32_t> probe((size_t)q * np), probe_n(q);
-    HIP_TRY(hipMemcpyAsync(probe.data(), d_probe, probe.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(probe_n.data(), d_probe_n, (size_t)q * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    // Work items.  A list is cut into runs of at most `run` row tiles, so that a long list (hub centroid) becomes
-    // many workgroups instead of one long one; every (query, probed list, run) owns a candidate list of its own,
-    // numbered consecutively per query: query i owns lists list_base[i] .. list_base[i+1]-1.  `run` doubles until the
-    // lists of the busiest query fit the merge kernel's LDS.
-    // Thresholds start from a sample of every query's nearest list (ivf_seed_tau_kernel).  The probe slots are then
-    // scanned in up to three launches (by default slots 0-3, then the rest); after each launch a query's threshold
-    // is raised to the (k+6)-th best score it has listed, so the far lists only list what can still matter.
-    auto tiles_of = [&](uint32_t l) { return round_up(ix->list_len[l], TILE_ROWS) / TILE_ROWS; };
     const uint32_t max_lists_per_query = std::max<uint32_t>(np, 2048);  // bounds the list bookkeeping, not correctness
     const uint32_t item_queries = bf16 ? flat_scan_bf16_queries_per_block(flat_scan_bf16_dpad(ix->dim)) : (uint32_t)TILE_QUERIES;
     uint32_t run = 8;
-    std::vector<uint32_t> list_base(q + 1, 0);
-    uint32_t busiest = 0;
-    for (;;) {
-        busiest = 0;
-        for (uint32_t i = 0; i < q; ++i) {
-            uint32_t cnt = 0;
-            for (uint32_t sl = 0; sl < probe_n[i]; ++sl) cnt += std::max<uint32_t>(1, (tiles_of(probe[(size_t)i * np + sl]) + run - 1) / run);
-            list_base[i + 1] = list_base[i] + cnt;
-            busiest = std::max(busiest, cnt);
-        }
-        if (busiest <= max_lists_per_query || run >= (1u << 20)) break;
-        run *= 2;
+    for (; run < (1u << 20); run *= 2) {
+        uint64_t worst = 0;
+        for (uint32_t i = 0; i < np; ++i) worst += std::max<uint32_t>(1, (ix->list_tiles_desc[i] + run - 1) / run);
+        if (worst <= max_lists_per_query) break;
     }
-    const uint32_t total_lists = list_base[q] * lpe;  // device numbering: entry y owns lists lpe*y .. lpe*y + lpe-1
     uint32_t bounds[4] = {0, 0, std::min<uint32_t>(4, np), np};  // with seeded thresholds: slots 0-3, refresh, the rest
     if (const char* dbg = getenv("NEEDLE_HIP_DEBUG_IVF_STAGES")) {  // development: "a,b" = slot bounds of launches 1 and 2
         unsigned a = 0, b = 0;
         if (sscanf(dbg, "%u,%u", &a, &b) == 2) { bounds[1] = std::min<uint32_t>(a, np); bounds[2] = std::min<uint32_t>(std::max(a, b), np); }
     }
-    std::vector<uint2> itemq;
-    std::vector<IvfItem> items;
-    uint32_t item_end[3] = {0, 0, 0};
-    std::vector<uint32_t> slot_first((size_t)q * np);  // first candidate list of (query, slot)
-    for (uint32_t i = 0; i < q; ++i) {
-        uint32_t at = list_base[i];
-        for (uint32_t sl = 0; sl < probe_n[i]; ++sl) {
-            slot_first[(size_t)i * np + sl] = at;
-            at += std::max<uint32_t>(1, (tiles_of(probe[(size_t)i * np + sl]) + run - 1) / run);
-        }
+    RegroupBufs rg{};
+    {
+        const uint32_t SL = 3 * ix->nlist;
+        const size_t words = (size_t)4 * SL + 2 + (size_t)q + (size_t)q + 1 + (size_t)q * np + 8;
+        HIP_TRY(ix->v_regroup.ensure(words * sizeof(uint32_t)));
+        uint32_t* w = ix->v_regroup.as<uint32_t>();
+        rg.cnt = w; rg.fill = w + SL; rg.pair_off = w + 2 * (size_t)SL; rg.item_off = rg.pair_off + SL + 1;
+        rg.qlists = rg.item_off + SL + 1; rg.lbase = rg.qlists + q; rg.slot_rel = rg.lbase + q + 1;
+        rg.totals = rg.slot_rel + (size_t)q * np;
+        HIP_TRY(hipMemsetAsync(rg.cnt, 0, (size_t)2 * SL * sizeof(uint32_t), c->stream));
     }
-    for (int r = 0; r < 3; ++r) {
-        const uint32_t s0 = bounds[r], s1 = bounds[r + 1];
-        if (s1 > s0) {
-            std::vector<uint32_t> per_list(ix->nlist + 1, 0);
-            for (uint32_t i = 0; i < q; ++i)
-                for (uint32_t sl = s0; sl < std::min(s1, probe_n[i]); ++sl) per_list[probe[(size_t)i * np + sl] + 1] += 1;
-            for (uint32_t l = 0; l < ix->nlist; ++l) per_list[l + 1] += per_list[l];
-            std::vector<uint2> pairs(per_list[ix->nlist]);  // (query, slot) by list, ascending query index inside a list
-            {
-                std::vector<uint32_t> fill(per_list.begin(), per_list.end() - 1);
-                for (uint32_t i = 0; i < q; ++i)
-                    for (uint32_t sl = s0; sl < std::min(s1, probe_n[i]); ++sl)
-                        pairs[fill[probe[(size_t)i * np + sl]]++] = make_uint2(i, sl);
-            }
-            for (uint32_t l = 0; l < ix->nlist; ++l) {
-                const uint32_t cnt = per_list[l + 1] - per_list[l];
-                if (cnt == 0 || ix->list_len[l] == 0) continue;
-                const uint32_t t0 = ix->list_pos[l] / TILE_ROWS, nt = tiles_of(l);
-                for (uint32_t ch = 0; ch * run < nt; ++ch) {
-                    const uint32_t base = (uint32_t)itemq.size();
-                    for (uint32_t e = 0; e < cnt; ++e) {
-                        const uint2 pr = pairs[per_list[l] + e];
-                        itemq.push_back(make_uint2(pr.x, slot_first[(size_t)pr.x * np + pr.y] + ch));
-                    }
-                    for (uint32_t o = 0; o < cnt; o += item_queries)
-                        items.push_back(IvfItem{t0 + ch * run, t0 + std::min(nt, (ch + 1) * run), base + o,
-                                                std::min<uint32_t>(item_queries, cnt - o)});
-                }
-            }
-        }
-        item_end[r] = (uint32_t)items.size();
-    }
+    HIP_TRY(ix->v_lbase.ensure((size_t)(q + 1) * sizeof(uint32_t)));
+    HIP_TRY(ix->v_itemq.ensure(std::max<size_t>((size_t)q * np, 1) * sizeof(uint2)));
+    rg.lbase_dev = ix->v_lbase.as<uint32_t>();
+    rg.probe = d_probe; rg.probe_n = d_probe_n; rg.list_len = ix->d_list_len; rg.list_pos = ix->d_list_pos;
+    rg.q = q; rg.np = np; rg.nlist = ix->nlist; rg.run = run; rg.item_queries = item_queries; rg.lpe = lpe;
+    rg.b1 = bounds[1]; rg.b2 = bounds[2];
+    hipLaunchKernelGGL(ivf_regroup_count_kernel, dim3((q + 255) / 256), dim3(256), 0, c->stream, rg);
+    hipLaunchKernelGGL(ivf_regroup_scan_kernel, dim3(1), dim3(1024), 0, c->stream, rg);
+    HIP_TRY(hipGetLastError());
+    uint32_t totals[8] = {0};
+    HIP_TRY(hipMemcpyAsync(totals, rg.totals, sizeof(totals), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint32_t total_lists = totals[0] * lpe;  // device numbering: entry y owns lists lpe*y .. lpe*y + lpe-1
+    const uint32_t item_end[3] = {totals[1], totals[2], totals[3]};
+    const uint32_t busiest = totals[4], n_items = totals[3];
+    HIP_TRY(ix->v_items.ensure(std::max<size_t>(n_items, 1) * sizeof(IvfItem)));
+    rg.itemq = ix->v_itemq.as<uint2>();
+    rg.items = ix->v_items.as<IvfItem>();
+    hipLaunchKernelGGL(ivf_regroup_scatter_kernel, dim3((q * np + 255) / 256), dim3(256), 0, c->stream, rg);
+    hipLaunchKernelGGL(ivf_regroup_items_kernel, dim3((3 * ix->nlist + 255) / 256), dim3(256), 0, c->stream, rg);
+    HIP_TRY(hipGetLastError());
 
     const double t_items_done = now();
     if (bf16) ST_TRY(ensure_bf16_copy(ix));
@@ -383,21 +473,11 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     if (bf16) HIP_TRY(ix->w_qerr.ensure((size_t)q * sizeof(float)));
     HIP_TRY(ix->w_lists.ensure((size_t)std::max<uint32_t>(total_lists, 1) * cap * sizeof(uint2)));
     HIP_TRY(ix->w_lcnt.ensure((size_t)std::max<uint32_t>(total_lists, 1) * sizeof(uint32_t)));
-    HIP_TRY(ix->v_lbase.ensure((size_t)(q + 1) * sizeof(uint32_t)));
-    std::vector<uint32_t> list_base_dev(q + 1);
-    for (uint32_t i = 0; i <= q; ++i) list_base_dev[i] = list_base[i] * lpe;
-    HIP_TRY(hipMemcpyAsync(ix->v_lbase.p, list_base_dev.data(), (size_t)(q + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(ix->w_cand.ensure((size_t)q * kprime * sizeof(uint32_t)));
     HIP_TRY(ix->w_candn.ensure((size_t)q * sizeof(uint32_t)));
     HIP_TRY(ix->w_tau.ensure((size_t)q * sizeof(float)));
     HIP_TRY(ix->w_flagged.ensure((size_t)q * sizeof(uint32_t)));
     HIP_TRY(ix->w_flagcnt.ensure(sizeof(uint32_t)));
-    HIP_TRY(ix->v_items.ensure(std::max<size_t>(items.size(), 1) * sizeof(IvfItem)));
-    HIP_TRY(ix->v_itemq.ensure(std::max<size_t>(itemq.size(), 1) * sizeof(uint2)));
-    if (!items.empty())
-        HIP_TRY(hipMemcpyAsync(ix->v_items.p, items.data(), items.size() * sizeof(IvfItem), hipMemcpyHostToDevice, c->stream));
-    if (!itemq.empty())
-        HIP_TRY(hipMemcpyAsync(ix->v_itemq.p, itemq.data(), itemq.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(ix->w_qop.p, 0, (size_t)q * dpad * elt, c->stream));
     HIP_TRY(hipMemsetAsync(ix->w_lcnt.p, 0, (size_t)std::max<uint32_t>(total_lists, 1) * sizeof(uint32_t), c->stream));
     HIP_TRY(hipMemsetAsync(ix->w_flagcnt.p, 0, sizeof(uint32_t), c->stream));
@@ -484,8 +564,8 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
         dbg_listed = (double)tot / q;
     }
     if (dbg_t)
-        fprintf(stderr, "[needle_hip] ivf: %u queries, %zu items, %u candidate lists (busiest query %u, run %u tiles); probe %.2f ms, "
-                "host regroup %.2f ms, device scan+post %.2f ms, undecided %u, listed %.1f per query\n", q, items.size(), total_lists,
+        fprintf(stderr, "[needle_hip] ivf: %u queries, %u items, %u candidate lists (busiest query %u, run %u tiles); probe %.2f ms, "
+                "regroup %.2f ms, device scan+post %.2f ms, undecided %u, listed %.1f per query\n", q, n_items, total_lists,
                 busiest, run, t_probe_done - t_entry, t_items_done - t_probe_done, now() - t_items_done, n_flagged, dbg_listed);
     if (c->profiling) {
         float ms = 0.0f;

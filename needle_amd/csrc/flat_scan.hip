@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
         if (q_live) {
             const uint2 e = iq[jq];
             my_query = e.x;
-            list_idx = e.y;
+            list_idx = e.y + it.list_add;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

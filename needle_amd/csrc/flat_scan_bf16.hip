@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
             q_live[nt] = jq < it.nq;
             const uint2 e = q_live[nt] ? iq[jq] : make_uint2(0u, 0u);
             my_query[nt] = e.x;
-            list_idx[nt] = e.y * 2 + h;  // every lane half owns a list
+            list_idx[nt] = (e.y + it.list_add) * 2 + h;  // every lane half owns a list
         }
     } else {
         uint32_t q_tile;

@@ -89,6 +89,7 @@ struct needle_hip_index {
     needle_hip_index* centroids = nullptr;  // flat Euclidean index over the centroids (probing)
     uint32_t nlist = 0;
     std::vector<uint32_t> list_pos, list_len;  // start position (multiple of 128) and rows of every list
+    std::vector<uint32_t> list_tiles_desc;     // row tiles of every list, largest first (bounds a query's candidate lists)
     uint32_t* d_list_pos = nullptr;
     uint32_t* d_list_len = nullptr;
     uint32_t* d_pos2id = nullptr;  // [n_pad] row id of a position, ~0 for padding
@@ -107,7 +108,7 @@ struct needle_hip_index {
     nh::DevBuf w_qerr;  // [q_pad] |query operand - its bf16 copy|
     nh::DevBuf r_idx, r_q, r_ids, r_dists, r_cnt;  // queries a reduced-precision pass could not decide, re-run in fp32
     nh::DevBuf x_keys, x_u32, x_u64, x_sel, x_mask;
-    nh::DevBuf v_probe_ids, v_probe_d, v_probe_n, v_probe32, v_items, v_itemq, v_lbase;
+    nh::DevBuf v_probe_ids, v_probe_d, v_probe_n, v_probe32, v_items, v_itemq, v_lbase, v_regroup;
 };
 
 namespace nh {

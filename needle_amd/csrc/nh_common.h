@@ -94,6 +94,7 @@ __host__ __device__ inline double score_eps_sq8(double qconst, double vmax, doub
 struct IvfItem {
     uint32_t tile0, tile1;   // row tiles [tile0, tile1) of the list (lists are padded to whole tiles)
     uint32_t qoff, nq;       // entries [qoff, qoff + nq) of item_queries, nq <= TILE_QUERIES
+    uint32_t list_add;       // index of this run within its list: added to every entry's candidate list index
 };
 
 // ---- launch parameters of the first-pass scan ----------------------------
@@ -135,7 +136,7 @@ struct ScanParams {
     // inverted-list scan: one workgroup per work item = (one list's row tiles) x (<= 128 of the
     // queries probing that list); rows are positions in the list-ordered copy of the base
     const IvfItem* items;     // [grid]
-    const uint2* item_queries;  // (query index, index of the candidate list this entry fills) per item entry
+    const uint2* item_queries;  // (query index, candidate list of the entry's first run; + IvfItem::list_add) per item entry
     const uint32_t* pos2id;   // [n_pad] original row id of a position, ~0 for padding
     uint32_t base_is_u8;      // base_op is a u8 code matrix (scalar-quantized scan)
 };

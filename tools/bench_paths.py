@@ -8,7 +8,7 @@ the configurations BASELINE.json lists (one JSON line per path):
   sq8  SQ8 asymmetric scan over 6.25M x 384 codes (= 50M / 8), 1K queries, k=10
   pq   PQ m=48 table scan over 6.25M x 48 codes (= 50M / 8), 1K queries, k=10
 
-Inputs are synthetic (Gaussian rows; IVF centroids = a random sample of the rows, quantizer
+Inputs are synthetic (Gaussian rows; IVF centroids = 8 Lloyd iterations on a 100-rows-per-list sample, quantizer
 parameters trained on a sample; codes of the big sets are drawn uniformly, which is what a scan's
 cost depends on).  Queries and results live in HBM (device-pointer entry point).  A sample of each
 result is checked against the CPU oracle where the oracle finishes in seconds.
@@ -106,10 +106,25 @@ def flat_case(ctx, dev, name, n, dim, nq, k, metric, steps, filt_frac=None, orac
     ix.close()
 
 
-def ivf_case(ctx, dev, n, dim, nlist, nprobe, nq, k, steps, oracle=None):
+def lloyd_centroids(dev, sample, cents, iters):
+    """A few Lloyd iterations (torch, input generation only): balanced lists as a trained index has them."""
+    x = torch.from_numpy(sample).to(dev)
+    c = torch.from_numpy(cents).to(dev)
+    for _ in range(iters):
+        cn = (c * c).sum(1)
+        assign = torch.cat([(cn[None, :] - 2.0 * (x[s:s + 65536] @ c.T)).argmin(1) for s in range(0, x.shape[0], 65536)])
+        sums = torch.zeros_like(c).index_add_(0, assign, x)
+        cnt = torch.bincount(assign, minlength=c.shape[0])
+        c = torch.where(cnt[:, None] > 0, sums / cnt.clamp(min=1)[:, None].to(sums.dtype), c)
+    return np.ascontiguousarray(c.cpu().numpy())
+
+
+def ivf_case(ctx, dev, n, dim, nlist, nprobe, nq, k, steps, oracle=None, centroids="trained"):
     rng = np.random.default_rng(11)
     base = rng.standard_normal((n, dim), dtype=F)
     cents = np.ascontiguousarray(base[rng.choice(n, nlist, replace=False)])
+    if centroids == "trained":  # k-means on a sample of 100 rows per list, as an index is trained
+        cents = lloyd_centroids(dev, base[rng.choice(n, min(n, 100 * nlist), replace=False)], cents, 8)
     queries = rng.standard_normal((nq, dim), dtype=F)
     h = C.c_void_p()
     t0 = time.perf_counter()
@@ -131,7 +146,7 @@ def ivf_case(ctx, dev, n, dim, nlist, nprobe, nq, k, steps, oracle=None):
     bytes_once = int(padded[per_list > 0].sum()) * row_bytes                         # every probed list once
     bytes_unbatched = int((per_list * sizes.astype(np.int64)).sum()) * row_bytes     # per-query scans, as the reference
     pairs = int((per_list * sizes.astype(np.int64)).sum())
-    extra = {"list_scan": "bf16", "fp32_list_scan_ms_per_batch": round(sec32 * 1e3, 3), "build_s": round(build_s, 2),
+    extra = {"centroids": centroids, "largest_list": int(sizes.max()), "list_scan": "bf16", "fp32_list_scan_ms_per_batch": round(sec32 * 1e3, 3), "build_s": round(build_s, 2),
              "scanned_pairs": pairs,
              "bytes_listmajor": bytes_items, "bytes_each_probed_list_once": bytes_once, "bytes_unbatched": bytes_unbatched,
              "listmajor_GBps_over_whole_search": round(bytes_items / sec / 1e9, 1),
@@ -221,6 +236,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the row counts (smoke runs)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--ivf-centroids", default="trained", choices=["trained", "sampled"],
+                    help="trained: Lloyd iterations on a sample (balanced lists); sampled: raw rows (hub lists)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -239,7 +256,8 @@ def main():
         flat_case(ctx, dev, "c5", int(1_000_000 * sc), 768, 1000, 100, na.DistanceFunction.DotProduct, args.steps,
                   filt_frac=0.1, oracle=oracle)
     if "ivf" in want:
-        ivf_case(ctx, dev, int(1_250_000 * sc), 384, max(16, int(4096 * sc)), 32, 10_000, 10, args.steps, oracle=oracle)
+        ivf_case(ctx, dev, int(1_250_000 * sc), 384, max(16, int(4096 * sc)), 32, 10_000, 10, args.steps, oracle=oracle,
+                 centroids=args.ivf_centroids)
     if "sq8" in want:
         sq8_case(ctx, dev, int(6_250_000 * sc), 384, 1000, 10, args.steps, oracle=oracle)
     if "pq" in want:
