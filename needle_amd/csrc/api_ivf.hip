@@ -37,39 +37,54 @@ __global__ __launch_bounds__(256) void ivf_gather_rows_kernel(const float* __res
     }
 }
 
+// Accumulator seeds of padding positions: -inf, so that a padding row scores -inf in every first pass and the list
+// scan needs no position -> id lookup to reject it (row_live<MODE_IVF>).
+__global__ void ivf_pad_seed_kernel(const uint32_t* __restrict__ pos2id, uint32_t n_pos, float* __restrict__ cinit) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pos && pos2id[i] == 0xffffffffu) cinit[i] = -INFINITY;
+}
+
 __global__ void ivf_narrow_probe_kernel(const uint64_t* __restrict__ ids, uint32_t total, uint32_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) out[i] = (uint32_t)ids[i];  // padding UINT64_MAX -> UINT32_MAX
 }
 
-// Starting thresholds of the list scan.  One wave per query scores (up to) the first IVF_SEED_ROWS rows of the
+// Starting thresholds of the list scan.  One workgroup (four waves) per query scores (up to) the first IVF_SEED_ROWS rows of the
 // query's nearest list with plain vector arithmetic, in the first pass's score units (q.b - |b|^2/2), and takes
 // the kseed-th largest score of live rows minus twice the score uncertainty: kseed live rows reach it, so the
 // scan may start from it (a lower rank or a shorter sample only makes the threshold weaker, never wrong).
-constexpr uint32_t IVF_SEED_ROWS = 256;
+constexpr uint32_t IVF_SEED_ROWS = 256;  // slots of the sample; the launch passes how many rows it scores
 
-__global__ __launch_bounds__(64) void ivf_seed_tau_kernel(const float* __restrict__ queries, const float* __restrict__ rows,
-                                                          const float* __restrict__ cinit, const uint32_t* __restrict__ probe,
-                                                          const uint32_t* __restrict__ probe_n, uint32_t np,
-                                                          const uint32_t* __restrict__ list_pos,
-                                                          const uint32_t* __restrict__ list_len,
-                                                          const uint32_t* __restrict__ pos2id, const uint32_t* __restrict__ valid,
-                                                          const uint32_t* __restrict__ filter, uint32_t dim, uint32_t kseed,
-                                                          nh::TauBand band, float* __restrict__ tau) {
-    __shared__ uint32_t ord[IVF_SEED_ROWS];
-    const uint32_t q = blockIdx.x, lane = threadIdx.x;
-    float t = -INFINITY;
-    if (probe_n[q] > 0) {
+__device__ __forceinline__ float seed_elt(const float* r, uint64_t i) { return r[i]; }
+__device__ __forceinline__ float seed_elt(const uint16_t* r, uint64_t i) { return __uint_as_float((uint32_t)r[i] << 16); }
+
+template <typename T>  // rows: the f32 rows, or their bf16 copy (row stride ld elements)
+__global__ __launch_bounds__(256) void ivf_seed_tau_kernel(const float* __restrict__ queries, const T* __restrict__ rows, uint32_t ld,
+                                                           uint32_t sample_rows, const float* __restrict__ cinit, const uint32_t* __restrict__ probe,
+                                                           const uint32_t* __restrict__ probe_n, uint32_t np,
+                                                           const uint32_t* __restrict__ list_pos,
+                                                           const uint32_t* __restrict__ list_len,
+                                                           const uint32_t* __restrict__ pos2id, const uint32_t* __restrict__ valid,
+                                                           const uint32_t* __restrict__ filter, uint32_t dim, uint32_t kseed,
+                                                           nh::TauBand band, float* __restrict__ tau) {
+    __shared__ uint32_t ord[IVF_SEED_ROWS];  // order-preserving score bits; 0 (below every score) for dead or absent rows
+    __shared__ uint32_t n_live;
+    const uint32_t q = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) n_live = 0;
+    ord[threadIdx.x] = 0u;
+    __syncthreads();
+    if (probe_n[q] > 0) {  // block-uniform
         const uint32_t l = probe[(uint64_t)q * np];
-        const uint32_t p0 = list_pos[l], len = min(list_len[l], IVF_SEED_ROWS);
+        const uint32_t p0 = list_pos[l], len = min(list_len[l], min(sample_rows, IVF_SEED_ROWS));
         const float* qv = queries + (uint64_t)q * dim;
         uint32_t live = 0;
-        for (uint32_t r0 = 0; r0 < len; r0 += 4) {  // four rows per step: independent loads and reductions
+        // every wave scores 64 of the rows, four per step: independent loads and reductions
+        for (uint32_t r0 = wave * 64; r0 < min(len, wave * 64 + 64); r0 += 4) {
             float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             for (uint32_t i = lane; i < dim; i += 64) {
                 const float x = qv[i];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) s[j] += x * rows[(uint64_t)(p0 + min(r0 + j, len - 1)) * dim + i];
+                for (int j = 0; j < 4; ++j) s[j] += x * seed_elt(rows, (uint64_t)(p0 + min(r0 + j, len - 1)) * ld + i);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -83,28 +98,31 @@ __global__ __launch_bounds__(64) void ivf_seed_tau_kernel(const float* __restric
                 if (ok && valid) ok = nh::bit_set(valid, id);
                 if (ok && filter) ok = nh::bit_set(filter, id);
                 if (ok) {  // wave-uniform
-                    if (lane == 0) ord[live] = nh::f2ord(s[j] + cinit[p0 + r]);
+                    if (lane == 0) ord[r] = nh::f2ord(s[j] + cinit[p0 + r]);
                     live += 1;
                 }
             }
         }
-        __syncthreads();
-        if (live >= kseed) {
-            uint32_t prefix = 0;
-            for (int bit = 31; bit >= 0; --bit) {
-                const uint32_t trial = prefix | (1u << bit);
-                uint32_t cnt = 0;
-                for (uint32_t i = 0; i < live; i += 64) {
-                    const bool ge = (i + lane < live) && (ord[i + lane] >= trial);
-                    cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ge));
-                }
-                if (cnt >= kseed) prefix = trial;
-            }
-            const double qn = sqrt(band.qn2[q]);
-            const double lowp = nh::bf16_score_err(band.metric, qn, band.bmax, band.qerr ? (double)band.qerr[q] : -1.0, band.berr);
-            const float tb = (float)((double)nh::ord2f(prefix) - 2.0 * nh::score_eps(band.metric, lowp, qn, band.bmax, band.dim));
-            if (tb == tb) t = tb;
+        if (lane == 0 && live) atomicAdd(&n_live, live);
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    float t = -INFINITY;
+    if (n_live >= kseed) {
+        uint32_t prefix = 0;
+        const uint32_t o0 = ord[lane], o1 = ord[64 + lane], o2 = ord[128 + lane], o3 = ord[192 + lane];
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t trial = prefix | (1u << bit);  // > 0: never counts an empty slot
+            const uint32_t cnt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(o0 >= trial)) +
+                                 __builtin_popcountll(__builtin_amdgcn_ballot_w64(o1 >= trial)) +
+                                 __builtin_popcountll(__builtin_amdgcn_ballot_w64(o2 >= trial)) +
+                                 __builtin_popcountll(__builtin_amdgcn_ballot_w64(o3 >= trial));
+            if (cnt >= kseed) prefix = trial;
         }
+        const double qn = sqrt(band.qn2[q]);
+        const double lowp = nh::bf16_score_err(band.metric, qn, band.bmax, band.qerr ? (double)band.qerr[q] : -1.0, band.berr);
+        const float tb = (float)((double)nh::ord2f(prefix) - 2.0 * nh::score_eps(band.metric, lowp, qn, band.bmax, band.dim));
+        if (tb == tb) t = tb;
     }
     if (lane == 0) tau[q] = t;
 }
@@ -311,6 +329,13 @@ extern "C" needle_hip_status needle_hip_ivf_build(needle_hip_ctx* c, const float
     if (d_src) (void)hipFree(d_src);
     if (e != hipSuccess) st = hip_fail(e, "building the IVF layout");
     if (st == NEEDLE_HIP_OK) st = finish_operands(ix, false);
+    if (st == NEEDLE_HIP_OK && ix->n_pad > 0 && ix->d_cinit) {
+        hipLaunchKernelGGL(ivf_pad_seed_kernel, dim3((ix->n_pad + 255) / 256), dim3(256), 0, c->stream, ix->d_pos2id, ix->n_pad,
+                           ix->d_cinit);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) st = hip_fail(e, "seeding the padding positions");
+    }
     if (st == NEEDLE_HIP_OK) st = upload_mask(ix, valid_bitmask);
     if (st == NEEDLE_HIP_OK)
         st = needle_hip_flat_build(c, centroids, nlist, dim, NEEDLE_METRIC_EUCLIDEAN, NEEDLE_ARITH_DISTANCE_RS, nullptr,
@@ -512,9 +537,18 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     band.berr = ix->bf16_err;
     band.dim = ix->dim; band.metric = ix->metric; band.precision = scan_precision;
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    hipLaunchKernelGGL(ivf_seed_tau_kernel, dim3(q), dim3(64), 0, c->stream, d_queries, ix->d_raw, ix->d_cinit, d_probe, d_probe_n,
-                       np, ix->d_list_pos, ix->d_list_len, ix->d_pos2id, ix->d_valid, d_filter, ix->dim, sp.kseed, band,
-                       ix->w_tau0.as<float>());
+    {
+        uint32_t sample_rows = IVF_SEED_ROWS;  // fewer rows: weaker thresholds, lists that overflow and are cut back often (measured: 2x the scan time at 128)
+        if (const char* e = getenv("NEEDLE_HIP_DEBUG_IVF_SEED_ROWS")) sample_rows = std::min<uint32_t>((uint32_t)atoi(e), IVF_SEED_ROWS);
+        if (bf16)
+            hipLaunchKernelGGL(ivf_seed_tau_kernel<uint16_t>, dim3(q), dim3(256), 0, c->stream, d_queries, (const uint16_t*)ix->d_op_bf16,
+                               dpad, sample_rows, ix->d_cinit, d_probe, d_probe_n, np, ix->d_list_pos, ix->d_list_len, ix->d_pos2id,
+                               ix->d_valid, d_filter, ix->dim, sp.kseed, band, ix->w_tau0.as<float>());
+        else
+            hipLaunchKernelGGL(ivf_seed_tau_kernel<float>, dim3(q), dim3(256), 0, c->stream, d_queries, (const float*)ix->d_raw, ix->dim,
+                               sample_rows, ix->d_cinit, d_probe, d_probe_n, np, ix->d_list_pos, ix->d_list_len, ix->d_pos2id,
+                               ix->d_valid, d_filter, ix->dim, sp.kseed, band, ix->w_tau0.as<float>());
+    }
     HIP_TRY(hipGetLastError());
     for (int r = 0; r < 3; ++r) {
         const uint32_t i0 = r ? item_end[r - 1] : 0u, i1 = item_end[r];

@@ -18,6 +18,9 @@ __device__ inline uint32_t row_of_reg(int r, uint32_t h) { return (r & 3) + 8 * 
 template <int MODE>
 __device__ inline bool row_live(const ScanParams& p, uint32_t row) {
     if (MODE == MODE_IVF) {
+        // padding positions of an inverted list carry an accumulator seed of -inf (set when the index is built), so
+        // they never score above a threshold: without masks no lookup is needed
+        if (!p.valid && !p.filter) return true;
         const uint32_t id = p.pos2id[row];
         if (id == 0xffffffffu) return false;
         if (p.valid && !bit_set(p.valid, id)) return false;
