@@ -9,19 +9,24 @@ walks an HNSW graph (approximate); this one is the exact scan that its
 `brute_force_search` / `compute_ground_truth` define, keeping the k NEAREST
 rows (the reference's brute-force heap evicts the nearest).
 Filters are applied as an exact pre-filter, not as a post-filter of an
-over-fetched candidate list.
+over-fetched candidate list: `Filter` (needle_amd/metadata.py) is evaluated on
+the host into a row bitmask (equality on indexed fields through the inverted
+index), deleted and expired rows (src/collection/ttl.rs) are masked the same
+way, and the GPU scan never scores a masked row.
 """
 from __future__ import annotations
 
 import dataclasses
 import math
-from typing import Any, Callable, Dict, List, Optional, Sequence
+import time
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
 from . import _lib
 from .distance import DistanceFunction
 from .index import Context, FlatIndex, _f32
+from .metadata import Filter, MetadataStore
 
 
 @dataclasses.dataclass
@@ -31,22 +36,36 @@ class SearchResult:  # src/collection/search.rs:39-52
     metadata: Optional[Any] = None
 
 
+def _same_mask(a: Optional[np.ndarray], b: Optional[np.ndarray]) -> bool:
+    if a is None or b is None:
+        return a is None and b is None
+    return a.shape == b.shape and bool(np.array_equal(a, b))
+
+
 class Collection:
     def __init__(self, name: str, dimensions: int, distance: DistanceFunction = DistanceFunction.Cosine, *,
-                 device: int = 0, ctx: Context | None = None, precision: str = "fp32"):
+                 device: int = 0, ctx: Context | None = None, precision: str = "fp32",
+                 default_ttl_seconds: Optional[int] = None, lazy_expiration: bool = True,
+                 clock: Callable[[], float] = time.time):
         self.name = name
         self.dimensions = dimensions
         self.distance = DistanceFunction(distance)
         self.precision = precision
-        self.ctx = ctx or Context(device)
+        self._ctx, self._device = ctx, device   # the device context is created on the first search
+        self.default_ttl_seconds = default_ttl_seconds   # CollectionConfig::default_ttl_seconds
+        self.lazy_expiration = lazy_expiration           # CollectionConfig::lazy_expiration (config.rs:396, default true)
+        self._clock = clock                              # Collection::now_unix, ttl.rs:8-13 (injectable for tests)
         self._vectors: List[np.ndarray] = []     # internal id -> row (VectorStore)
         self._external: List[str] = []           # internal id -> external id
         self._metadata: List[Optional[Any]] = []
         self._by_external: Dict[str, int] = {}
         self._deleted: List[bool] = []
+        self._store = MetadataStore()            # entries + equality inverted index (metadata.rs)
+        self._expirations: Dict[int, int] = {}   # internal id -> unix second it expires at (ttl.rs)
         self._index: FlatIndex | None = None
         self._dirty = True
         self._mask_dirty = False
+        self._mask_sent: Optional[np.ndarray] = None
 
     # ---- validation.rs -------------------------------------------------------
     @staticmethod
@@ -70,36 +89,113 @@ class Collection:
         return len(self._vectors) - sum(self._deleted)
 
     # ---- mutation ------------------------------------------------------------
+    @property
+    def ctx(self) -> Context:
+        if self._ctx is None:
+            self._ctx = Context(self._device)
+        return self._ctx
+
+    def now_unix(self) -> int:
+        return int(self._clock())
+
     def insert(self, id: str, vector: Sequence[float], metadata: Optional[Any] = None) -> None:
+        self.insert_with_ttl(id, vector, metadata, self.default_ttl_seconds)  # insert_vec, insert.rs:103-110
+
+    def insert_with_ttl(self, id: str, vector: Sequence[float], metadata: Optional[Any] = None,
+                        ttl_seconds: Optional[int] = None) -> None:  # insert.rs:89-97, 116-
         self.validate_query(vector)  # validate_insert_input, validation.rs:44-52
         if id in self._by_external:
             raise ValueError(f"Vector already exists: {id}")
-        self._by_external[id] = len(self._vectors)
+        internal = len(self._vectors)
+        self._store.insert(internal, id, metadata)
+        self._by_external[id] = internal
         self._vectors.append(_f32(vector))
         self._external.append(id)
         self._metadata.append(metadata)
         self._deleted.append(False)
+        if ttl_seconds is not None:
+            self._expirations[internal] = self.now_unix() + int(ttl_seconds)
         self._dirty = True
 
+    def _drop(self, internal: int) -> None:
+        self._by_external.pop(self._external[internal], None)
+        self._store.delete(internal)
+        self._expirations.pop(internal, None)
+        self._deleted[internal] = True
+        self._mask_dirty = True
+
     def delete(self, id: str) -> bool:
-        i = self._by_external.pop(id, None)
+        i = self._by_external.get(id)
         if i is None:
             return False
-        self._deleted[i] = True
-        self._mask_dirty = True
+        self._drop(i)
         return True
 
+    # ---- TTL: src/collection/ttl.rs ---------------------------------------------
+    def is_expired(self, internal_id: int) -> bool:  # ttl.rs:17-23
+        exp = self._expirations.get(internal_id)
+        return exp is not None and self.now_unix() >= exp
+
+    def expire_vectors(self) -> int:  # ttl.rs:52-78: the eager sweep
+        now = self.now_unix()
+        gone = [i for i, exp in self._expirations.items() if now >= exp]
+        for i in gone:
+            self._drop(i)
+        return len(gone)
+
+    def needs_expiration_sweep(self, threshold: float) -> bool:  # ttl.rs:101-115
+        if not self._expirations:
+            return False
+        now = self.now_unix()
+        expired = sum(1 for exp in self._expirations.values() if now >= exp)
+        total = len(self)
+        return expired > 0 if total == 0 else (expired / total) > threshold
+
+    def ttl_stats(self) -> Tuple[int, int, Optional[int], Optional[int]]:  # ttl.rs:130-138
+        now = self.now_unix()
+        vals = list(self._expirations.values())
+        return (len(vals), sum(1 for e in vals if now >= e), min(vals) if vals else None, max(vals) if vals else None)
+
+    def get_ttl(self, id: str) -> Optional[int]:  # ttl.rs:143-146
+        i = self._by_external.get(id)
+        return None if i is None else self._expirations.get(i)
+
+    def set_ttl(self, id: str, ttl_seconds: Optional[int]) -> None:  # ttl.rs:158-175
+        i = self._by_external.get(id)
+        if i is None:
+            raise KeyError(f"Vector not found: {id}")  # NeedleError::VectorNotFound
+        if ttl_seconds is None:
+            self._expirations.pop(i, None)
+        else:
+            self._expirations[i] = self.now_unix() + int(ttl_seconds)
+
+    # ---- resident index and its live-row mask --------------------------------------
+    def _live_mask(self) -> Optional[np.ndarray]:
+        """Rows the scan may score: not deleted (search_methods.rs:205) and, with lazy expiration, not
+        expired at this moment (search_methods.rs:210); None when every row is live."""
+        expired = []
+        if self.lazy_expiration and self._expirations:
+            now = self.now_unix()
+            expired = [i for i, exp in self._expirations.items() if now >= exp]
+        if not expired and not any(self._deleted):
+            return None
+        live = ~np.array(self._deleted, dtype=np.bool_)
+        live[expired] = False
+        return live
+
     def _resident(self) -> FlatIndex:
+        live = self._live_mask()
         if self._dirty or self._index is None:
             if self._index is not None:
                 self._index.close()
             base = np.stack(self._vectors) if self._vectors else np.zeros((0, self.dimensions), dtype=np.float32)
-            self._index = FlatIndex(self.ctx, base, self.distance, dim=self.dimensions,
-                                    valid=None if not any(self._deleted) else ~np.array(self._deleted))
+            self._index = FlatIndex(self.ctx, base, self.distance, dim=self.dimensions, valid=live)
             self._dirty = self._mask_dirty = False
-        elif self._mask_dirty:
-            self._index.set_valid_mask(~np.array(self._deleted) if any(self._deleted) else None)
+            self._mask_sent = live
+        elif self._mask_dirty or not _same_mask(live, self._mask_sent):
+            self._index.set_valid_mask(live)
             self._mask_dirty = False
+            self._mask_sent = live
         return self._index
 
     # ---- search --------------------------------------------------------------
@@ -122,11 +218,24 @@ class Collection:
         ids, dists, counts = self._resident().search(_f32(queries), k, precision=self.precision)
         return [self._enrich(ids[i], dists[i], counts[i]) for i in range(len(queries))]
 
+    def filter_mask(self, filter: Union[Filter, dict, Callable[[Optional[Any]], bool]]) -> np.ndarray:
+        """bool per internal id: the rows `filter` lets through.  A `Filter` (or its JSON form) goes
+        through the metadata store (inverted index for equality on indexed fields, Filter::matches
+        otherwise); a plain callable is applied to every live entry's metadata."""
+        if isinstance(filter, dict):
+            filter = Filter.parse(filter)
+        if isinstance(filter, Filter):
+            return self._store.filter_bitmask(filter, len(self._vectors))
+        keep = np.zeros(len(self._vectors), dtype=np.bool_)
+        for i, (_, data) in self._store.entries.items():
+            keep[i] = bool(filter(data))
+        return keep
+
     def batch_search_with_filter(self, queries: Sequence[Sequence[float]], k: int,
-                                 filter: Callable[[Optional[Any]], bool]) -> List[List[SearchResult]]:
-        """Collection::batch_search_with_filter, src/collection/batch.rs:108-171; `filter` plays
-        Filter::matches(metadata).  Rows without a matching metadata entry are excluded
-        (search_methods.rs:215-223)."""
+                                 filter: Union[Filter, dict, Callable[[Optional[Any]], bool]]) -> List[List[SearchResult]]:
+        """Collection::batch_search_with_filter, src/collection/batch.rs:108-171; `filter` is a Filter, its
+        JSON form, or a callable playing Filter::matches(metadata).  Rows without a metadata entry are
+        excluded (search_methods.rs:215-223)."""
         for q in queries:
             self.validate_query(q)
         k = self.clamp_k(k)
@@ -134,6 +243,6 @@ class Collection:
             return [[] for _ in queries]
         if len(queries) == 0:
             return []
-        keep = np.array([bool(filter(m)) for m in self._metadata], dtype=np.bool_)
+        keep = self.filter_mask(filter)
         ids, dists, counts = self._resident().search(_f32(queries), k, precision=self.precision, filter_mask=keep)
         return [self._enrich(ids[i], dists[i], counts[i]) for i in range(len(queries))]

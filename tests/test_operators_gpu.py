@@ -203,3 +203,44 @@ def test_collection_batch_search(ctx, oracle, precision):
     assert col.batch_search(queries, 0) == [[] for _ in range(17)]
     assert col.batch_search([], 5) == []
     assert len(col.search(queries[0], 10_000)) == len(col)  # clamp_k
+
+
+def test_collection_filter_objects_and_ttl(ctx, oracle):
+    """Filter (JSON form, builders, inverted-index path) and lazy expiration produce the row masks; the scan
+    then returns exactly the oracle's pre-filtered result (search_methods.rs:205-223, ttl.rs:17-23)."""
+    import needle_amd as na
+    from needle_amd.collection import Collection
+    from needle_amd.metadata import Filter
+
+    rng = np.random.default_rng(21)
+    n, dim = 2500, 48
+    rows = rng.standard_normal((n, dim)).astype(F)
+    now = [5000]
+    col = Collection("docs", dim, na.DistanceFunction.Euclidean, ctx=ctx, precision="bf16", clock=lambda: now[0])
+    meta = [{"group": i % 7, "tags": ["even" if i % 2 == 0 else "odd"], "info": {"score": i / n}} for i in range(n)]
+    for i in range(n):
+        col.insert_with_ttl(f"d{i}", rows[i], meta[i] if i % 50 else None, 100 if i % 3 == 0 else None)
+    queries = rng.standard_normal((9, dim)).astype(F)
+    met = int(na.DistanceFunction.Euclidean)
+
+    def check(res, keep, k):
+        oi, od, oc = oracle.flat_batch_search(queries, rows, k, met, valid=keep)
+        for i, hits in enumerate(res):
+            assert [h.id for h in hits] == [f"d{int(j)}" for j in oi[i, : oc[i]]]
+            assert np.array_equal(_bits([h.distance for h in hits]), _bits(od[i, : oc[i]]))
+
+    has_meta = np.array([i % 50 != 0 for i in range(n)])
+    grp = np.array([i % 7 for i in range(n)])
+    check(col.batch_search_with_filter(queries, 10, Filter.eq("group", 3)), has_meta & (grp == 3), 10)  # inverted index
+    check(col.batch_search_with_filter(queries, 10, {"$or": [{"group": {"$in": [1, 2]}}, {"info.score": {"$lt": 0.1}}]}),
+          has_meta & (np.isin(grp, [1, 2]) | (np.arange(n) / n < 0.1)), 10)
+    check(col.batch_search_with_filter(queries, 5, {"tags": {"$contains": "odd"}, "group": {"$ne": 0}}),
+          has_meta & (np.arange(n) % 2 == 1) & (grp != 0), 5)
+    check(col.batch_search_with_filter(queries, 5, Filter.exists("group", False)), ~has_meta, 5)
+    now[0] = 5100  # every third row has expired: masked lazily, still counted by len()
+    live = np.arange(n) % 3 != 0
+    assert len(col) == n
+    check(col.batch_search(queries, 10), live, 10)
+    check(col.batch_search_with_filter(queries, 10, Filter.eq("group", 3)), live & has_meta & (grp == 3), 10)
+    assert col.expire_vectors() == int((~live).sum()) and len(col) == int(live.sum())
+    check(col.batch_search(queries, 10), live, 10)
