@@ -227,6 +227,25 @@ needle_hip_status needle_hip_pq_build(needle_hip_ctx* ctx, const uint8_t* codes,
                                       uint32_t m, const float* codebooks, const uint32_t* valid_bitmask,
                                       needle_hip_index** out);
 
+/* ---- binary codes -------------------------------------------------------- */
+
+/* A 1-bit-per-dimension code matrix scanned by Hamming distance: BinaryQuantizer,
+ * src/indexing/quantization.rs:536-594, searched as its call site does
+ * (src/indexing/compression_advisor.rs:658-671: all distances, stable sort, first
+ * k).  codes: n x ceil(dim / 8) host bytes (BinaryQuantizer::quantize output: bit
+ * i % 8 of byte i / 8 set iff v[i] > thresholds[i], :574-585); thresholds: [dim]
+ * host f32 (:538).  needle_hip_batch_search on this index quantizes every f32
+ * query with the same rule and returns the k rows of smallest Hamming distance
+ * (reported as f32, exact), ties to the lower row id (k <= 1024). */
+needle_hip_status needle_hip_binary_build(needle_hip_ctx* ctx, const uint8_t* codes, uint64_t n, uint32_t dim,
+                                          const float* thresholds, const uint32_t* valid_bitmask,
+                                          needle_hip_index** out);
+
+/* BinaryQuantizer::quantize (quantization.rs:574-585) of n host vectors on the
+ * device: out_codes receives n x ceil(dim / 8) bytes. */
+needle_hip_status needle_hip_binary_quantize(needle_hip_ctx* ctx, const float* thresholds, const float* vectors,
+                                             uint64_t n, uint32_t dim, uint8_t* out_codes);
+
 /* A u8 code matrix scored with ScalarQuantizer::asymmetric_distance,
  * src/indexing/quantization.rs:277-285: sqrt(sum_j (q_j - (c_j / scale_j + min_j))^2).
  * codes: n x dim host bytes (ScalarQuantizer::quantize output, :219-238);

@@ -167,7 +167,7 @@ void nh::index_free(needle_hip_index* ix) {
     for (DevBuf* b : {&ix->w_qraw, &ix->w_qop, &ix->w_qn2, &ix->w_lists, &ix->w_lcnt, &ix->w_cand, &ix->w_candn,
                       &ix->w_tau, &ix->w_flagged, &ix->w_flagcnt, &ix->w_filter, &ix->w_premax, &ix->w_tau0, &ix->x_keys, &ix->x_u32,
                       &ix->x_u64, &ix->x_sel, &ix->x_mask, &ix->v_probe_ids, &ix->v_probe_d, &ix->v_probe_n, &ix->v_probe32,
-                      &ix->v_items, &ix->v_itemq, &ix->v_lbase, &ix->w_qerr, &ix->r_idx, &ix->r_q, &ix->r_ids, &ix->r_dists, &ix->r_cnt})
+                      &ix->v_items, &ix->v_itemq, &ix->v_lbase, &ix->w_qerr, &ix->r_idx, &ix->r_q, &ix->r_ids, &ix->r_dists, &ix->r_cnt, &ix->v_regroup, &ix->b_work})
         b->release();
     delete ix;
 }
@@ -738,6 +738,10 @@ static needle_hip_status search_device_locked(needle_hip_index* ix, const float*
                 ST_TRY(pq_search_batch_device(ix, d_queries + (size_t)q0 * ix->dim, qb, k, d_filter,
                                               d_out_ids + (size_t)q0 * k, d_out_dists + (size_t)q0 * k,
                                               d_out_counts + q0));
+            else if (ix->kind == KIND_BINARY)
+                ST_TRY(binary_search_batch_device(ix, d_queries + (size_t)q0 * ix->dim, qb, k, d_filter,
+                                                  d_out_ids + (size_t)q0 * k, d_out_dists + (size_t)q0 * k,
+                                                  d_out_counts + q0));
             else if (ix->kind == KIND_IVF)
                 ST_TRY(ivf_search_batch_device(ix, d_queries + (size_t)q0 * ix->dim, qb, k, params->nprobe, precision,
                                                d_filter, d_out_ids + (size_t)q0 * k, d_out_dists + (size_t)q0 * k,

@@ -65,7 +65,7 @@ struct needle_hip_ctx {
     nh::DevBuf scratch[4];  // operator-level calls
 };
 
-enum IndexKind { KIND_FLAT = 0, KIND_IVF = 1, KIND_PQ = 2, KIND_SQ8 = 3 };
+enum IndexKind { KIND_FLAT = 0, KIND_IVF = 1, KIND_PQ = 2, KIND_SQ8 = 3, KIND_BINARY = 4 };
 
 struct needle_hip_index {
     needle_hip_ctx* ctx = nullptr;
@@ -97,6 +97,7 @@ struct needle_hip_index {
     uint8_t* d_codes = nullptr;    // PQ: [n][pq_m]; SQ8: [n_pad][dpad_f32] zero padded
     float* d_codebooks = nullptr;  // PQ: [pq_m][256][pq_dsub]
     uint32_t pq_m = 0, pq_dsub = 0;
+    uint32_t bin_words = 0;        // binary codes: 64-bit words per row; d_codes holds [bin_words][n_pad] words, d_sq_min the thresholds
     float* d_sq_min = nullptr;     // SQ8: [dim] min_vals
     float* d_sq_scale = nullptr;   // SQ8: [dim] scale
     float* d_sq_inv = nullptr;     // SQ8: [dpad] 1/scale, zero padded (first-pass query scaling)
@@ -109,6 +110,7 @@ struct needle_hip_index {
     nh::DevBuf r_idx, r_q, r_ids, r_dists, r_cnt;  // queries a reduced-precision pass could not decide, re-run in fp32
     nh::DevBuf x_keys, x_u32, x_u64, x_sel, x_mask;
     nh::DevBuf v_probe_ids, v_probe_d, v_probe_n, v_probe32, v_items, v_itemq, v_lbase, v_regroup;
+    nh::DevBuf b_work;  // binary scan: query codes, histograms, tie counts, collected keys
 };
 
 namespace nh {
@@ -129,6 +131,10 @@ void index_free(needle_hip_index* ix);
 needle_hip_status finish_operands(needle_hip_index* ix, bool validate);
 needle_hip_status upload_mask(needle_hip_index* ix, const uint32_t* mask_host);
 // quantized scans of one batch (api_adc.hip)
+// Hamming scan of a binary code matrix (binary.hip)
+needle_hip_status binary_search_batch_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k,
+                                             const uint32_t* d_filter, uint64_t* d_out_ids, float* d_out_dists,
+                                             uint32_t* d_out_counts);
 needle_hip_status pq_search_batch_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k,
                                          const uint32_t* d_filter, uint64_t* d_out_ids, float* d_out_dists,
                                          uint32_t* d_out_counts);

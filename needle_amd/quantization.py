@@ -123,6 +123,45 @@ class ProductQuantizer:
         return np.concatenate([self.codebooks[s, c[s]] for s in range(self.num_subvectors)]).astype(F)
 
 
+class BinaryQuantizer:
+    """BinaryQuantizer, src/indexing/quantization.rs:536-594: one bit per dimension, set where the value
+    exceeds the dimension's threshold (the training mean)."""
+
+    def __init__(self, thresholds):
+        self.thresholds = np.ascontiguousarray(thresholds, dtype=F)
+        self.dimensions = self.thresholds.size
+
+    @classmethod
+    def train(cls, vectors) -> "BinaryQuantizer":  # quantization.rs:545-571: sequential f32 sums, one divide
+        v = np.ascontiguousarray(vectors, dtype=F)
+        if v.size == 0:
+            return cls(np.zeros(0, dtype=F))
+        acc = np.zeros(v.shape[1], dtype=F)
+        for row in v:
+            acc = (acc + row).astype(F)
+        return cls(acc / F(v.shape[0]))
+
+    def quantize(self, vectors) -> np.ndarray:  # quantization.rs:574-585: bit i % 8 of byte i / 8
+        v = np.ascontiguousarray(vectors, dtype=F)
+        single = v.ndim == 1
+        v2 = v.reshape(1, -1) if single else v
+        codes = np.packbits(v2 > self.thresholds[None, :], axis=1, bitorder="little")
+        return codes[0] if single else codes
+
+    def quantize_device(self, ctx: Context, vectors) -> np.ndarray:
+        """The same codes computed on the GPU (needle_hip_binary_quantize)."""
+        v = np.ascontiguousarray(vectors, dtype=F)
+        out = np.zeros((v.shape[0], (self.dimensions + 7) // 8), dtype=np.uint8)
+        _lib.check(_lib.lib().needle_hip_binary_quantize(ctx._h, self.thresholds.ctypes.data, v.ctypes.data, v.shape[0],
+                                                         self.dimensions, out.ctypes.data))
+        return out
+
+    @staticmethod
+    def hamming_distance(a, b) -> int:  # quantization.rs:588-593
+        x = np.bitwise_xor(np.asarray(a, dtype=np.uint8), np.asarray(b, dtype=np.uint8))
+        return int(np.unpackbits(x).sum())
+
+
 class _CodeIndex:
     def __init__(self):
         self._h = C.c_void_p()
@@ -189,3 +228,19 @@ class Sq8Index(_CodeIndex):
         _lib.check(_lib.lib().needle_hip_sq8_build(ctx._h, c.ctypes.data if self.n else None, self.n, sq.dimensions,
                                                    sq.min_vals.ctypes.data, sq.scale.ctypes.data,
                                                    vm.ctypes.data if vm is not None else None, C.byref(self._h)))
+
+
+class BinaryIndex(_CodeIndex):
+    """Resident binary code matrix scanned by Hamming distance; queries are f32 vectors, quantized on the
+    device with the index's thresholds (src/indexing/compression_advisor.rs:658-671)."""
+
+    def __init__(self, ctx: Context, bq: BinaryQuantizer, codes, valid=None):
+        super().__init__()
+        c = np.ascontiguousarray(codes, dtype=np.uint8)
+        if c.ndim != 2 or c.shape[1] != (bq.dimensions + 7) // 8:
+            raise ValueError("codes must be [n, ceil(dimensions / 8)]")
+        self.ctx, self.bq, self.n = ctx, bq, c.shape[0]
+        vm = _mask_words(valid, self.n)
+        _lib.check(_lib.lib().needle_hip_binary_build(ctx._h, c.ctypes.data if self.n else None, self.n, bq.dimensions,
+                                                      bq.thresholds.ctypes.data,
+                                                      vm.ctypes.data if vm is not None else None, C.byref(self._h)))

@@ -1067,6 +1067,30 @@ NDL_API float ndl_pq_distance_with_table(const float *table, const uint8_t *code
  *   kind 1: ProductQuantizer table scan: compute_distance_table once per
  *           query, distance_with_table per row, over u8[N][m]
  */
+/* ---- BinaryQuantizer, src/indexing/quantization.rs:536-594 ------------------------------- */
+/* train (:545-571): thresholds = per-dimension mean, summed sequentially in f32, one divide by n as f32 */
+NDL_API void ndl_bq_train(const float *vectors, size_t n, size_t dim, float *thresholds) {
+    for (size_t j = 0; j < dim; ++j) thresholds[j] = 0.0f;
+    if (n == 0) return;
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = 0; j < dim; ++j) thresholds[j] = thresholds[j] + vectors[i * dim + j];
+    const float nf = (float)n;
+    for (size_t j = 0; j < dim; ++j) thresholds[j] = thresholds[j] / nf;
+}
+/* quantize (:574-585): bit i % 8 of byte i / 8 set iff v[i] > threshold[i] */
+NDL_API void ndl_bq_quantize(const float *v, size_t dim, const float *thresholds, uint8_t *out) {
+    const size_t nbytes = (dim + 7) / 8;
+    for (size_t b = 0; b < nbytes; ++b) out[b] = 0;
+    for (size_t i = 0; i < dim; ++i)
+        if (v[i] > thresholds[i]) out[i / 8] |= (uint8_t)(1u << (i % 8));
+}
+/* hamming_distance (:588-593) */
+NDL_API uint32_t ndl_bq_hamming(const uint8_t *a, const uint8_t *b, size_t nbytes) {
+    uint32_t d = 0;
+    for (size_t i = 0; i < nbytes; ++i) d += (uint32_t)__builtin_popcount((unsigned)(a[i] ^ b[i]));
+    return d;
+}
+
 typedef struct {
     int kind; const float *queries; size_t nq, dim; const uint8_t *codes; uint64_t n;
     const float *p0, *p1; size_t m, k; const uint32_t *valid;
@@ -1076,6 +1100,8 @@ typedef struct {
 static void *adc_worker(void *arg) {
     adc_job *jb = (adc_job *)arg;
     float *table = jb->kind == 1 ? (float *)malloc(sizeof(float) * jb->m * 256) : NULL;
+    const size_t nbytes = (jb->dim + 7) / 8;
+    uint8_t *qbits = jb->kind == 2 ? (uint8_t *)malloc(nbytes ? nbytes : 1) : NULL;
     for (;;) {
         pthread_mutex_lock(&jb->mu);
         size_t q = jb->next++;
@@ -1085,10 +1111,12 @@ static void *adc_worker(void *arg) {
         ndl_heap hp; hp.n = 0; hp.cap = jb->k;
         hp.h = (ndl_hit *)malloc(sizeof(ndl_hit) * (jb->k + 1));
         if (jb->kind == 1) ndl_pq_distance_table(query, jb->dim, jb->m, jb->p0, table);
+        if (jb->kind == 2) ndl_bq_quantize(query, jb->dim, jb->p0, qbits);
         for (uint64_t i = 0; i < jb->n && jb->k; ++i) {
             if (jb->valid && !bit_get(jb->valid, i)) continue;
             ndl_hit x; x.id = i;
             if (jb->kind == 0) x.d = ndl_sq_asymmetric(query, jb->codes + i * jb->dim, jb->dim, jb->p0, jb->p1);
+            else if (jb->kind == 2) x.d = (float)ndl_bq_hamming(qbits, jb->codes + i * nbytes, nbytes);
             else x.d = ndl_pq_distance_with_table(table, jb->codes + i * jb->m, jb->m);
             heap_offer(&hp, x);
         }
@@ -1101,6 +1129,7 @@ static void *adc_worker(void *arg) {
         free(hp.h);
     }
     free(table);
+    free(qbits);
     return NULL;
 }
 static void adc_run(adc_job *jb, int threads) {
@@ -1118,6 +1147,16 @@ NDL_API void ndl_sq_batch_search(const float *queries, size_t nq, size_t dim,
                                  int threads, uint64_t *out_ids, float *out_dists,
                                  uint32_t *out_counts) {
     adc_job jb = {0, queries, nq, dim, codes, n, min_vals, scale, 0, k, valid,
+                  out_ids, out_dists, out_counts, 0, PTHREAD_MUTEX_INITIALIZER};
+    adc_run(&jb, threads);
+}
+/* the search of src/indexing/compression_advisor.rs:658-671: quantize the query, Hamming distance to every
+ * code, stable sort by distance, first k == order (distance, row index) */
+NDL_API void ndl_bq_batch_search(const float *queries, size_t nq, size_t dim,
+                                 const uint8_t *codes, uint64_t n, const float *thresholds,
+                                 size_t k, const uint32_t *valid, int threads, uint64_t *out_ids,
+                                 float *out_dists, uint32_t *out_counts) {
+    adc_job jb = {2, queries, nq, dim, codes, n, thresholds, NULL, 0, k, valid,
                   out_ids, out_dists, out_counts, 0, PTHREAD_MUTEX_INITIALIZER};
     adc_run(&jb, threads);
 }

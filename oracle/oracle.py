@@ -123,6 +123,14 @@ def _declare(L: C.CDLL) -> None:
     L.ndl_sq_batch_search.restype = None
     L.ndl_sq_batch_search.argtypes = [_f32p, sz, sz, _u8p, C.c_uint64, _f32p, _f32p, sz, _u32p, C.c_int, _u64p,
                                       _f32p, _u32p]
+    L.ndl_bq_train.restype = None
+    L.ndl_bq_train.argtypes = [_f32p, sz, sz, _f32p]
+    L.ndl_bq_quantize.restype = None
+    L.ndl_bq_quantize.argtypes = [_f32p, sz, _f32p, _u8p]
+    L.ndl_bq_hamming.restype = C.c_uint32
+    L.ndl_bq_hamming.argtypes = [_u8p, _u8p, sz]
+    L.ndl_bq_batch_search.restype = None
+    L.ndl_bq_batch_search.argtypes = [_f32p, sz, sz, _u8p, C.c_uint64, _f32p, sz, _u32p, C.c_int, _u64p, _f32p, _u32p]
     L.ndl_pq_batch_search.restype = None
     L.ndl_pq_batch_search.argtypes = [_f32p, sz, sz, _u8p, C.c_uint64, sz, _f32p, sz, _u32p, C.c_int, _u64p, _f32p,
                                       _u32p]
@@ -523,5 +531,53 @@ class ProductQuantizer:
         counts = np.zeros(nq, dtype=np.uint32)
         vk, vp = _mask_ptr(valid, n)
         lib().ndl_pq_batch_search(_p(q, _f32p), nq, dim, _p(c, _u8p), n, self.m, _p(self.codebooks, _f32p), k, vp,
+                                  threads or cpu_threads(), _p(ids, _u64p), _p(dists, _f32p), _p(counts, _u32p))
+        return ids[:, :k], dists[:, :k], counts
+
+
+class BinaryQuantizer:
+    """BinaryQuantizer of src/indexing/quantization.rs:536-594 and its search call site
+    (src/indexing/compression_advisor.rs:658-671)."""
+
+    def __init__(self, thresholds):
+        self.thresholds = _f32(thresholds)
+        self.dimensions = self.thresholds.size
+
+    @classmethod
+    def train(cls, vectors):
+        v = _f32(vectors)
+        if v.size == 0:
+            return cls(np.zeros(0, dtype=np.float32))
+        t = np.empty(v.shape[1], dtype=np.float32)
+        lib().ndl_bq_train(_p(v, _f32p), v.shape[0], v.shape[1], _p(t, _f32p))
+        return cls(t)
+
+    def quantize(self, vectors) -> np.ndarray:
+        v = _f32(vectors)
+        single = v.ndim == 1
+        v2 = v.reshape(1, -1) if single else v
+        out = np.zeros((v2.shape[0], (self.dimensions + 7) // 8), dtype=np.uint8)
+        for i in range(v2.shape[0]):
+            lib().ndl_bq_quantize(_p(v2[i], _f32p), self.dimensions, _p(self.thresholds, _f32p),
+                                  out[i].ctypes.data_as(_u8p))
+        return out[0] if single else out
+
+    @staticmethod
+    def hamming_distance(a, b) -> int:
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        b = np.ascontiguousarray(b, dtype=np.uint8)
+        return int(lib().ndl_bq_hamming(_p(a, _u8p), _p(b, _u8p), min(a.size, b.size)))
+
+    def batch_search(self, queries, codes, k: int, valid=None, threads: int | None = None):
+        q = _f32(queries)
+        c = np.ascontiguousarray(codes, dtype=np.uint8)
+        nq, dim = q.shape
+        n = c.shape[0]
+        kk = max(k, 1)
+        ids = np.full((nq, kk), np.iinfo(np.uint64).max, dtype=np.uint64)
+        dists = np.full((nq, kk), np.inf, dtype=np.float32)
+        counts = np.zeros(nq, dtype=np.uint32)
+        vk, vp = _mask_ptr(valid, n)
+        lib().ndl_bq_batch_search(_p(q, _f32p), nq, dim, _p(c, _u8p), n, _p(self.thresholds, _f32p), k, vp,
                                   threads or cpu_threads(), _p(ids, _u64p), _p(dists, _f32p), _p(counts, _u32p))
         return ids[:, :k], dists[:, :k], counts

@@ -122,3 +122,52 @@ def test_sq8_masks_duplicates_and_constant_dims(ctx, oracle):
     m2 = ctx.metrics()
     assert m2["refined_queries"] + m2["fallback_queries"] >= 1  # the duplicate cluster goes down the refinement chain
     ix.close()
+
+
+@pytest.mark.parametrize("shape", [(5000, 64, 10), (30000, 384, 10), (2000, 37, 7), (70000, 100, 100), (3000, 1000, 5)])
+def test_binary_hamming_scan(ctx, oracle, shape):
+    """BinaryQuantizer codes scanned by Hamming distance: (distance, row id) order of the reference's stable
+    sort (compression_advisor.rs:658-671); ties are the rule with integer distances."""
+    from needle_amd.quantization import BinaryIndex, BinaryQuantizer
+
+    n, dim, k = shape
+    rng = np.random.default_rng(n + dim)
+    base = rng.standard_normal((n, dim)).astype(F)
+    obq = oracle.BinaryQuantizer.train(base[: max(50, n // 10)])
+    bq = BinaryQuantizer.train(base[: max(50, n // 10)])
+    assert np.array_equal(bq.thresholds.view(np.uint32), obq.thresholds.view(np.uint32))
+    codes = obq.quantize(base)
+    assert np.array_equal(bq.quantize(base[:300]), codes[:300])
+    assert np.array_equal(bq.quantize_device(ctx, base[:300]), codes[:300])  # device encoder
+    queries = rng.standard_normal((37, dim)).astype(F)
+    ix = BinaryIndex(ctx, bq, codes)
+    _cmp(ix.search(queries, k), obq.batch_search(queries, codes, k))
+    ix.close()
+
+
+def test_binary_masks_ties_and_edges(ctx, oracle):
+    from needle_amd.quantization import BinaryIndex, BinaryQuantizer
+
+    rng = np.random.default_rng(9)
+    n, dim = 20000, 24  # 24 bits: at most 25 distinct distances, thousands of ties at the k-th
+    base = rng.standard_normal((n, dim)).astype(F)
+    obq = oracle.BinaryQuantizer.train(base)
+    codes = obq.quantize(base)
+    codes[5000:5200] = codes[3]
+    queries = rng.standard_normal((21, dim)).astype(F)
+    queries[0] = base[3]
+    valid = rng.random(n) > 0.25
+    filt = (np.arange(n) % 10) == 0
+    bq = BinaryQuantizer(obq.thresholds)
+    ix = BinaryIndex(ctx, bq, codes, valid=valid)
+    for k in (1, 12, 256, 1000):
+        _cmp(ix.search(queries, k), obq.batch_search(queries, codes, k, valid=valid))
+    _cmp(ix.search(queries, 12, filter_mask=filt), obq.batch_search(queries, codes, 12, valid=valid & filt))
+    none = np.zeros(n, dtype=bool)
+    assert ix.search(queries, 5, filter_mask=none)[2].tolist() == [0] * 21
+    ids, _, counts = ix.search(queries, 0)
+    assert ids.shape == (21, 0) and counts.tolist() == [0] * 21
+    ix.close()
+    small = BinaryIndex(ctx, bq, codes[:5])
+    _cmp(small.search(queries, 10), obq.batch_search(queries, codes[:5], 10))  # k > n
+    small.close()

@@ -372,3 +372,26 @@ def test_evict_nearest_forensic_mode(oracle):
     far, _, _ = oracle.flat_batch_search(q, base, 3, oracle.EUCLIDEAN, evict_nearest=True)
     assert near[0].tolist() == [0, 1, 2]
     assert far[0].tolist() == [7, 8, 9]
+
+
+# ---- BinaryQuantizer: src/indexing/quantization.rs:1085-1101, 1228-1252 ------------------------
+def test_kat_binary_quantizer(oracle):
+    from needle_amd.quantization import BinaryQuantizer as HostBq
+
+    vectors = np.array([[0.0, 1.0, 0.0, 1.0], [0.5, 0.5, 0.5, 0.5], [1.0, 0.0, 1.0, 0.0]], dtype=np.float32)
+    for bq in (oracle.BinaryQuantizer.train(vectors), HostBq.train(vectors)):
+        assert np.array_equal(bq.thresholds, np.full(4, 0.5, dtype=np.float32))
+        c1, c2 = bq.quantize(vectors[0]), bq.quantize(vectors[2])
+        assert c1.tolist() == [0b1010] and c2.tolist() == [0b0101]      # bit i % 8 of byte i / 8 (:578-581)
+        assert bq.hamming_distance(c1, c2) == 4 > 0                      # :1100-1101
+        assert bq.hamming_distance([0xFF], [0xFF]) == 0                  # :1236-1239
+        assert bq.hamming_distance([0x00], [0xFF]) == 8                  # :1242-1245
+        assert bq.hamming_distance([], []) == 0                          # :1248-1251
+    assert oracle.BinaryQuantizer.train(np.zeros((0, 0), dtype=np.float32)).dimensions == 0  # :1230-1233
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal((500, 37)).astype(np.float32)
+    o, h = oracle.BinaryQuantizer.train(v), HostBq.train(v)
+    assert np.array_equal(o.thresholds.view(np.uint32), h.thresholds.view(np.uint32))  # sequential f32 means
+    assert np.array_equal(o.quantize(v), h.quantize(v)) and o.quantize(v).shape == (500, 5)
+    ids, d, c = o.batch_search(v[:3], o.quantize(v), 4)
+    assert ids[:, 0].tolist() == [0, 1, 2] and d[:, 0].tolist() == [0.0, 0.0, 0.0] and c.tolist() == [4, 4, 4]
