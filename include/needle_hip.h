@@ -214,6 +214,20 @@ needle_hip_status needle_hip_ivf_list_sizes(const needle_hip_index* index, uint3
  * ivf.rs:509-567, with params->nprobe: the k nearest rows of the probed lists
  * by (distance, id). */
 
+/* ---- training ------------------------------------------------------------- */
+
+/* IvfIndex::train's k-means, src/indexing/ivf.rs:330-450: k-means++ seeding,
+ * Lloyd iterations (stop: no assignment changed, largest centroid shift <
+ * tolerance, or max_iterations), empty clusters re-seeded from a random row.
+ * The reference draws from thread_rng; here every draw comes from
+ * splitmix64(seed), so a run is reproducible.  vectors: n x dim host f32;
+ * out_centroids: room for min(n_clusters, n) x dim; *out_k receives the number
+ * of centroids produced (ivf.rs caps n_clusters at n).  Distances, cluster sums
+ * (row order) and the divide keep the reference's scalar arithmetic. */
+needle_hip_status needle_hip_ivf_train(needle_hip_ctx* ctx, const float* vectors, uint64_t n, uint32_t dim,
+                                       uint32_t n_clusters, uint32_t max_iterations, float tolerance,
+                                       uint64_t seed, float* out_centroids, uint32_t* out_k);
+
 /* ---- quantized (ADC) indexes ------------------------------------------- */
 
 /* A code matrix scored with ProductQuantizer::{compute_distance_table,

@@ -1,12 +1,11 @@
 """Host-side mirror of the reference's `IvfIndex` / `IvfConfig` (src/indexing/ivf.rs:106-567) over the
 device IVF index: same method names, argument meaning and error behaviour.
 
-Search and assignment run on the GPU (needle_hip_ivf_build / needle_hip_batch_search /
-needle_hip_kmeans_assign).  Training keeps the reference's control flow (k-means++ seeding, Lloyd,
-`tolerance` on the largest centroid shift, empty clusters re-seeded) with the assignment step on the
-GPU; the reference seeds from `thread_rng`, here the generator is seeded, so centroids are
-reproducible but not comparable to any reference run (they are not part of the parity contract:
-search parity is defined for given centroids).
+Search, assignment and training run on the GPU (needle_hip_ivf_build / needle_hip_batch_search /
+needle_hip_kmeans_assign / needle_hip_ivf_train).  Training keeps the reference's control flow
+(k-means++ seeding, Lloyd, `tolerance` on the largest centroid shift, empty clusters re-seeded) and
+arithmetic; the reference draws from `thread_rng`, here the generator is seeded, so centroids are
+reproducible but not comparable to any reference run (search parity is defined for given centroids).
 """
 from __future__ import annotations
 
@@ -90,42 +89,13 @@ class IvfIndex:
         if v.shape[0] == 0:
             raise ValueError("Empty training data")  # IvfError::EmptyTrainingData
         self._check_dim(v)
-        rng = np.random.default_rng(self.seed)
-        n = v.shape[0]
-        k = min(self.config.n_clusters, n)
-        cents = [v[rng.integers(n)].copy()]
-        dist = np.full(n, np.finfo(np.float32).max, dtype=np.float32)
-        for _ in range(1, k):  # k-means++: weights = (distance to the nearest chosen centroid)^2
-            d = np.sqrt(((v - cents[-1]) ** 2).sum(axis=1, dtype=np.float32))
-            dist = np.minimum(dist, d)
-            w = dist.astype(np.float64) ** 2
-            total = w.sum()
-            if total == 0.0:
-                rest = np.flatnonzero(dist > 0)
-                if rest.size == 0:
-                    break
-                cents.append(v[rng.choice(rest)].copy())
-            else:
-                cents.append(v[min(int(np.searchsorted(np.cumsum(w), rng.random() * total)), n - 1)].copy())
-        c = np.stack(cents).astype(np.float32)
-        assign = np.full(n, -1, dtype=np.int64)
-        for _ in range(self.config.max_iterations):
-            new_assign = self.ctx.kmeans_assign(v, c, _lib.ARITH_DISTANCE_RS).astype(np.int64)  # GPU
-            if np.array_equal(new_assign, assign):
-                break
-            assign = new_assign
-            new_c = np.zeros_like(c)
-            np.add.at(new_c, assign, v)
-            counts = np.bincount(assign, minlength=c.shape[0])
-            for j in range(c.shape[0]):
-                if counts[j] > 0:
-                    new_c[j] /= np.float32(counts[j])
-                else:
-                    new_c[j] = v[rng.integers(n)]
-            shift = float(np.sqrt(((new_c - c) ** 2).sum(axis=1)).max())
-            c = new_c
-            if shift < self.config.tolerance:
-                break
+        k = min(self.config.n_clusters, v.shape[0])
+        c = np.zeros((k, self.dimensions), dtype=np.float32)
+        got = C.c_uint32(0)
+        _lib.check(_lib.lib().needle_hip_ivf_train(self.ctx._h, v.ctypes.data, v.shape[0], self.dimensions,
+                                                   self.config.n_clusters, self.config.max_iterations,
+                                                   self.config.tolerance, self.seed, c.ctypes.data, C.byref(got)))
+        c = np.ascontiguousarray(c[: got.value])
         self.centroids = c
         self._dirty = True
 

@@ -167,3 +167,29 @@ def test_gpu_training_produces_usable_centroids(ctx, oracle):
     res = ix.search(blobs[5], 3)
     assert res[0][0] == 5 and res[0][1] == 0.0
     ix.close()
+
+
+@pytest.mark.parametrize("shape", [(2000, 16, 12, 100), (6000, 40, 64, 8), (300, 8, 400, 5)])
+def test_training_matches_the_seeded_cpu_kmeans(ctx, oracle, shape):
+    """needle_hip_ivf_train against the oracle's restatement of IvfIndex::kmeans (ivf.rs:330-450) with the same
+    splitmix64 draws: k-means++ picks, assignments, row-order cluster sums and the stop rules all agree, so the
+    centroids are bit-equal."""
+    from needle_amd.ivf import IvfConfig, IvfIndex
+
+    n, d, nlist, iters = shape
+    rng = np.random.default_rng(n)
+    blobs = rng.standard_normal((8, d)).astype(F) * F(4.0)
+    data = (blobs[rng.integers(0, 8, n)] + rng.standard_normal((n, d)).astype(F)).astype(F)
+    data[50:60] = data[7]  # duplicates: zero-distance rows in the seeding weights
+    for seed in (1, 12345):
+        want = oracle.ivf_kmeans(data, nlist, max_iter=iters, tol=1e-4, seed=seed)
+        ix = IvfIndex(d, IvfConfig.new(nlist).with_max_iterations(iters), ctx=ctx, seed=seed)
+        ix.train(data)
+        # capped at n (ivf.rs:909-921), and at the number of distinct rows (seeding stops when none is left)
+        assert ix.centroids.shape == want.shape == (min(nlist, n - 10), d)
+        assert np.array_equal(ix.centroids.view(np.uint32), want.view(np.uint32))
+    ix.add(range(n), data)
+    assert int(ix.cluster_sizes().sum()) == n  # ivf.rs:788-805
+    with pytest.raises(ValueError):
+        ix.train(np.zeros((0, d), dtype=F))
+    ix.close()

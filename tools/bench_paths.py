@@ -7,6 +7,7 @@ the configurations BASELINE.json lists (one JSON line per path):
   ivf  IVF-Flat nlist=4096 nprobe=32 over 1.25M x 384 (= 10M / 8 GPUs), 10K queries, k=10
   sq8  SQ8 asymmetric scan over 6.25M x 384 codes (= 50M / 8), 1K queries, k=10
   pq   PQ m=48 table scan over 6.25M x 48 codes (= 50M / 8), 1K queries, k=10
+  binary  1-bit codes, Hamming scan over 6.25M x 384 bits (= 50M / 8), 1K queries, k=10
 
 Inputs are synthetic (Gaussian rows; IVF centroids = 8 Lloyd iterations on a 100-rows-per-list sample, quantizer
 parameters trained on a sample; codes of the big sets are drawn uniformly, which is what a scan's
@@ -230,9 +231,40 @@ def pq_case(ctx, dev, n, dim, m_sub, nq, k, steps, oracle=None):
     ix.close()
 
 
+def binary_case(ctx, dev, n, dim, nq, k, steps, oracle=None):
+    rng = np.random.default_rng(19)
+    bq = na.quantization.BinaryQuantizer(np.zeros(dim, dtype=F))
+    nbytes = (dim + 7) // 8
+    codes = rng.integers(0, 256, size=(n, nbytes), dtype=np.uint8)
+    queries = rng.standard_normal((nq, dim), dtype=F)
+    ix = na.quantization.BinaryIndex(ctx, bq, codes)
+    dq = torch.from_numpy(queries).to(dev)
+    ctx.set_profiling(True)
+    ctx.reset_metrics()
+    sec, out = timed(lambda: search_device(ix._h, dq, k), steps, 1)
+    m = ctx.metrics()
+    ctx.set_profiling(False)
+    scan_ms = m["scan_ms_total"] / max(m["scan_launches"], 1)
+    qt = 16 if dim + 1 <= 900 else 4
+    byts = 3 * (-(-nq // qt)) * n * nbytes  # three scans (histogram, ties, collect), once per query tile
+    extra = {"scan_ms": round(scan_ms, 3), "bytes_scanned": byts, "scan_GBps": round(byts / scan_ms / 1e6, 1),
+             "frac_of_hbm_peak": round(byts / scan_ms / 1e6 / HBM_PEAK_GBS, 4),
+             "xor_popcount_words_per_s": round(3.0 * nq * n * ((dim + 63) // 64) / scan_ms / 1e9, 2)}
+    if oracle is not None:
+        s, ns = 8, 500_000
+        small = na.quantization.BinaryIndex(ctx, bq, codes[:ns])
+        gi, gd, gc = small.search(queries[:s], k)
+        oi, od, oc = oracle.BinaryQuantizer(bq.thresholds).batch_search(queries[:s], codes[:ns], k)
+        extra["parity"] = {"queries_checked": s, "rows": ns, "ids_equal": bool(np.array_equal(gi, oi)),
+                           "dists_bit_equal": bool(np.array_equal(bits(gd), bits(od)))}
+        small.close()
+    emit("binary", f"binary codes, Hamming scan over {n}x{dim} bits, k={k}", nq, sec, extra)
+    ix.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--paths", default="c1,c5,ivf,sq8,pq")
+    ap.add_argument("--paths", default="c1,c5,ivf,sq8,pq,binary")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the row counts (smoke runs)")
     ap.add_argument("--no-parity", action="store_true")
@@ -262,6 +294,8 @@ def main():
         sq8_case(ctx, dev, int(6_250_000 * sc), 384, 1000, 10, args.steps, oracle=oracle)
     if "pq" in want:
         pq_case(ctx, dev, int(6_250_000 * sc), 384, 48, 1000, 10, args.steps, oracle=oracle)
+    if "binary" in want:
+        binary_case(ctx, dev, int(6_250_000 * sc), 384, 1000, 10, args.steps, oracle=oracle)
     ctx.close()
 
 
