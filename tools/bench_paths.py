@@ -9,7 +9,7 @@ the configurations BASELINE.json lists (one JSON line per path):
   pq   PQ m=48 table scan over 6.25M x 48 codes (= 50M / 8), 1K queries, k=10
   binary  1-bit codes, Hamming scan over 6.25M x 384 bits (= 50M / 8), 1K queries, k=10
 
-Inputs are synthetic (Gaussian rows; IVF centroids = 8 Lloyd iterations on a 100-rows-per-list sample, quantizer
+Inputs are synthetic (Gaussian rows; IVF centroids = k-means++ and 8 Lloyd iterations on a 100-rows-per-list sample, trained on the device, quantizer
 parameters trained on a sample; codes of the big sets are drawn uniformly, which is what a scan's
 cost depends on).  Queries and results live in HBM (device-pointer entry point).  A sample of each
 result is checked against the CPU oracle where the oracle finishes in seconds.
@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import needle_amd as na  # noqa: E402
+import needle_amd.ivf  # noqa: E402,F401
 import needle_amd.quantization  # noqa: E402,F401
 from needle_amd import _lib  # noqa: E402
 from needle_amd.index import PRECISION, _mask_words  # noqa: E402
@@ -107,25 +108,20 @@ def flat_case(ctx, dev, name, n, dim, nq, k, metric, steps, filt_frac=None, orac
     ix.close()
 
 
-def lloyd_centroids(dev, sample, cents, iters):
-    """A few Lloyd iterations (torch, input generation only): balanced lists as a trained index has them."""
-    x = torch.from_numpy(sample).to(dev)
-    c = torch.from_numpy(cents).to(dev)
-    for _ in range(iters):
-        cn = (c * c).sum(1)
-        assign = torch.cat([(cn[None, :] - 2.0 * (x[s:s + 65536] @ c.T)).argmin(1) for s in range(0, x.shape[0], 65536)])
-        sums = torch.zeros_like(c).index_add_(0, assign, x)
-        cnt = torch.bincount(assign, minlength=c.shape[0])
-        c = torch.where(cnt[:, None] > 0, sums / cnt.clamp(min=1)[:, None].to(sums.dtype), c)
-    return np.ascontiguousarray(c.cpu().numpy())
+def trained_centroids(ctx, sample, nlist, iters, seed=11):
+    """IvfIndex::train on the device (needle_hip_ivf_train): k-means++ and `iters` Lloyd iterations."""
+    ix = na.ivf.IvfIndex(sample.shape[1], na.ivf.IvfConfig.new(nlist).with_max_iterations(iters), ctx=ctx, seed=seed)
+    t0 = time.perf_counter()
+    ix.train(sample)
+    return ix.centroids, time.perf_counter() - t0
 
 
 def ivf_case(ctx, dev, n, dim, nlist, nprobe, nq, k, steps, oracle=None, centroids="trained"):
     rng = np.random.default_rng(11)
     base = rng.standard_normal((n, dim), dtype=F)
-    cents = np.ascontiguousarray(base[rng.choice(n, nlist, replace=False)])
+    cents, train_s = np.ascontiguousarray(base[rng.choice(n, nlist, replace=False)]), 0.0
     if centroids == "trained":  # k-means on a sample of 100 rows per list, as an index is trained
-        cents = lloyd_centroids(dev, base[rng.choice(n, min(n, 100 * nlist), replace=False)], cents, 8)
+        cents, train_s = trained_centroids(ctx, base[rng.choice(n, min(n, 100 * nlist), replace=False)], nlist, 8)
     queries = rng.standard_normal((nq, dim), dtype=F)
     h = C.c_void_p()
     t0 = time.perf_counter()
@@ -147,7 +143,7 @@ def ivf_case(ctx, dev, n, dim, nlist, nprobe, nq, k, steps, oracle=None, centroi
     bytes_once = int(padded[per_list > 0].sum()) * row_bytes                         # every probed list once
     bytes_unbatched = int((per_list * sizes.astype(np.int64)).sum()) * row_bytes     # per-query scans, as the reference
     pairs = int((per_list * sizes.astype(np.int64)).sum())
-    extra = {"centroids": centroids, "largest_list": int(sizes.max()), "list_scan": "bf16", "fp32_list_scan_ms_per_batch": round(sec32 * 1e3, 3), "build_s": round(build_s, 2),
+    extra = {"centroids": centroids, "largest_list": int(sizes.max()), "list_scan": "bf16", "fp32_list_scan_ms_per_batch": round(sec32 * 1e3, 3), "build_s": round(build_s, 2), "train_s": round(train_s, 2),
              "scanned_pairs": pairs,
              "bytes_listmajor": bytes_items, "bytes_each_probed_list_once": bytes_once, "bytes_unbatched": bytes_unbatched,
              "listmajor_GBps_over_whole_search": round(bytes_items / sec / 1e9, 1),
