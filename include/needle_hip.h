@@ -228,6 +228,23 @@ needle_hip_status needle_hip_ivf_train(needle_hip_ctx* ctx, const float* vectors
                                        uint32_t n_clusters, uint32_t max_iterations, float tolerance,
                                        uint64_t seed, float* out_centroids, uint32_t* out_k);
 
+/* ProductQuantizer::train, src/indexing/quantization.rs:330-364 with its kmeans
+ * (:597-711): per subspace up to 256 centroids, seeding by squared distance to the
+ * nearest chosen centroid, `iterations` (reference: 20) Lloyd passes, on the raw
+ * sub-vectors; draws from splitmix64(seed) instead of thread_rng.  out_codebooks:
+ * [m][256][dim/m] host f32, zero beyond the centroids a subspace produced;
+ * out_ncent (nullable): [m] centroids produced (256 unless n < 256 or the rows
+ * hold fewer distinct sub-vectors). */
+needle_hip_status needle_hip_pq_train(needle_hip_ctx* ctx, const float* vectors, uint64_t n, uint32_t dim, uint32_t m,
+                                      uint32_t iterations, uint64_t seed, float* out_codebooks, uint32_t* out_ncent);
+
+/* ProductQuantizer::encode, quantization.rs:377-446, of n host vectors: per
+ * subspace the first centroid at minimum squared distance (strict '<' from
+ * f32::MAX).  ncent (nullable): centroids in use per subspace (256 when null).
+ * out_codes: n x m host bytes. */
+needle_hip_status needle_hip_pq_encode(needle_hip_ctx* ctx, const float* codebooks, uint32_t dim, uint32_t m,
+                                       const uint32_t* ncent, const float* vectors, uint64_t n, uint8_t* out_codes);
+
 /* ---- quantized (ADC) indexes ------------------------------------------- */
 
 /* A code matrix scored with ProductQuantizer::{compute_distance_table,

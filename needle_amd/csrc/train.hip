@@ -241,3 +241,261 @@ static needle_hip_status ivf_train_impl(needle_hip_ctx* c, const float* vectors,
     *out_k = k;
     return NEEDLE_HIP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Product quantizer: encoding and codebook training.
+//
+// Reference: ProductQuantizer::{train, encode, find_nearest_centroid}, src/indexing/quantization.rs:330-446, and its
+// kmeans, :597-711: per subspace 256 centroids, seeding weighted by the squared distance to the nearest chosen
+// centroid (normalised by the total, threshold walk), 20 Lloyd iterations with strict '<' from f32::MAX (first
+// minimum), empty clusters re-seeded from a random row.  Squared distances are the sequential sum of (a - b)^2.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float pq_l2sq(const float* __restrict__ a, const float* __restrict__ b, uint32_t n) {
+    float s = -0.0f;
+    for (uint32_t i = 0; i < n; ++i) { const float d = a[i] - b[i]; const float p = d * d; s = s + p; }
+    return s;
+}
+
+// nearest centroid of sub-vector (row, subspace blockIdx.y): codebook of the subspace in LDS, one thread per row
+template <int DSUB>  // 0: any width (the sub-vector is re-read through the cache)
+__global__ __launch_bounds__(256) void pq_encode_kernel(const float* __restrict__ v, uint32_t n, uint32_t dim, uint32_t dsub_rt,
+                                                        const float* __restrict__ codebooks, const uint32_t* __restrict__ ncent,
+                                                        uint32_t m, uint8_t* __restrict__ out) {
+    extern __shared__ float cb[];  // [256][dsub]
+    const uint32_t s = blockIdx.y, dsub = DSUB ? DSUB : dsub_rt;
+    const uint32_t k = ncent ? min(ncent[s], 256u) : 256u;
+    for (uint32_t i = threadIdx.x; i < 256 * dsub; i += 256) cb[i] = codebooks[(uint64_t)s * 256 * dsub + i];
+    __syncthreads();
+    const uint32_t row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= n) return;
+    const float* sub = v + (uint64_t)row * dim + s * dsub;
+    float x[DSUB ? DSUB : 1];
+    if (DSUB) {
+#pragma unroll
+        for (int j = 0; j < DSUB; ++j) x[j] = sub[j];
+    }
+    uint32_t best = 0;
+    float bd = 3.40282347e+38f;
+    for (uint32_t c = 0; c < k; ++c) {
+        float d;
+        if (DSUB) {
+            d = -0.0f;
+#pragma unroll
+            for (int j = 0; j < DSUB; ++j) { const float t = x[j] - cb[c * DSUB + j]; const float p = t * t; d = d + p; }
+        } else {
+            d = pq_l2sq(sub, cb + c * dsub, dsub);
+        }
+        if (d < bd) { bd = d; best = c; }
+    }
+    out[(uint64_t)row * m + s] = (uint8_t)best;
+}
+
+hipError_t launch_pq_encode(const float* d_v, uint32_t n, uint32_t dim, uint32_t m, const float* d_books, const uint32_t* d_ncent,
+                            uint8_t* d_out, hipStream_t stream) {
+    const uint32_t dsub = dim / m;
+    const dim3 grid((n + 255) / 256, m), block(256);
+    const size_t lds = (size_t)256 * dsub * sizeof(float);
+    switch (dsub) {
+    case 4: hipLaunchKernelGGL(pq_encode_kernel<4>, grid, block, lds, stream, d_v, n, dim, dsub, d_books, d_ncent, m, d_out); break;
+    case 8: hipLaunchKernelGGL(pq_encode_kernel<8>, grid, block, lds, stream, d_v, n, dim, dsub, d_books, d_ncent, m, d_out); break;
+    case 16: hipLaunchKernelGGL(pq_encode_kernel<16>, grid, block, lds, stream, d_v, n, dim, dsub, d_books, d_ncent, m, d_out); break;
+    default: hipLaunchKernelGGL(pq_encode_kernel<0>, grid, block, lds, stream, d_v, n, dim, dsub, d_books, d_ncent, m, d_out); break;
+    }
+    return hipGetLastError();
+}
+
+// seeding: dist[i] = min(dist[i], |sub-vector i - centroid|^2)
+__global__ __launch_bounds__(256) void pq_seed_distance_kernel(const float* __restrict__ v, uint32_t n, uint32_t dim, uint32_t off,
+                                                               uint32_t dsub, const float* __restrict__ centroid,
+                                                               float* __restrict__ dist) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    dist[i] = fminf(dist[i], pq_l2sq(v + (uint64_t)i * dim + off, centroid, dsub));
+}
+
+// Lloyd assignment: strict '<' from f32::MAX -> first minimum (quantization.rs:640-655)
+__global__ __launch_bounds__(256) void pq_assign_kernel(const float* __restrict__ v, uint32_t n, uint32_t dim, uint32_t off,
+                                                        uint32_t dsub, const float* __restrict__ cent, uint32_t k,
+                                                        uint32_t* __restrict__ assign) {
+    extern __shared__ float cb[];
+    for (uint32_t i = threadIdx.x; i < k * dsub; i += 256) cb[i] = cent[i];
+    __syncthreads();
+    const uint32_t row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= n) return;
+    const float* sub = v + (uint64_t)row * dim + off;
+    uint32_t best = 0;
+    float bd = 3.40282347e+38f;
+    for (uint32_t c = 0; c < k; ++c) {
+        const float d = pq_l2sq(sub, cb + c * dsub, dsub);
+        if (d < bd) { bd = d; best = c; }
+    }
+    assign[row] = best;
+}
+
+// cluster means of sub-vectors: row order, from 0.0, one divide (quantization.rs:660-690)
+__global__ __launch_bounds__(64) void pq_centroid_kernel(const float* __restrict__ v, uint32_t dim, uint32_t off, uint32_t dsub,
+                                                         const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
+                                                         float* __restrict__ out) {
+    const uint32_t c = blockIdx.x, b = offsets[c], e = offsets[c + 1];
+    if (e == b) return;
+    const float cnt = (float)(e - b);
+    for (uint32_t j = threadIdx.x; j < dsub; j += 64) {
+        float s = 0.0f;
+        for (uint32_t r = b; r < e; ++r) s = s + v[(uint64_t)order[r] * dim + off + j];
+        out[(uint64_t)c * dsub + j] = s / cnt;
+    }
+}
+
+needle_hip_status pq_train_impl(needle_hip_ctx* c, const float* vectors, uint64_t n, uint32_t dim, uint32_t m, uint32_t iterations,
+                                uint64_t seed, float* out_books, uint32_t* out_ncent) {
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t nn = (uint32_t)n, dsub = dim / m;
+    DevFree dev;
+    auto dmalloc = [&](void** p, size_t bytes) {
+        hipError_t e = hipMalloc(p, bytes ? bytes : 1);
+        if (e == hipSuccess) dev.p.push_back(*p);
+        return e;
+    };
+    float *d_v = nullptr, *d_dist = nullptr, *d_cent = nullptr, *d_newc = nullptr;
+    uint32_t *d_assign = nullptr, *d_order = nullptr, *d_off = nullptr;
+    HIP_TRY(dmalloc((void**)&d_v, (size_t)n * dim * sizeof(float)));
+    HIP_TRY(dmalloc((void**)&d_dist, (size_t)n * sizeof(float)));
+    HIP_TRY(dmalloc((void**)&d_cent, (size_t)256 * dsub * sizeof(float)));
+    HIP_TRY(dmalloc((void**)&d_newc, (size_t)256 * dsub * sizeof(float)));
+    HIP_TRY(dmalloc((void**)&d_assign, (size_t)n * sizeof(uint32_t)));
+    HIP_TRY(dmalloc((void**)&d_order, (size_t)n * sizeof(uint32_t)));
+    HIP_TRY(dmalloc((void**)&d_off, 257 * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpyAsync(d_v, vectors, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    memset(out_books, 0, (size_t)m * 256 * dsub * sizeof(float));
+    uint64_t rs = seed;
+    const uint32_t kmax = std::min<uint32_t>(256, nn);
+    std::vector<float> cent((size_t)256 * dsub), newc((size_t)256 * dsub), dist(n);
+    std::vector<uint32_t> assign(n), fresh(n), order(n), offsets(257);
+    auto sub = [&](uint64_t i, uint32_t s) { return vectors + i * dim + (size_t)s * dsub; };
+    for (uint32_t s = 0; s < m; ++s) {
+        const uint32_t off = s * dsub;
+        // ---- seeding, quantization.rs:603-637 ----
+        memcpy(cent.data(), sub(splitmix64(rs) % n, s), sizeof(float) * dsub);
+        uint32_t nc = 1;
+        hipLaunchKernelGGL(tr_fill_kernel, dim3((nn + 255) / 256), dim3(256), 0, c->stream, d_dist, nn, 3.40282347e+38f);
+        HIP_TRY(hipGetLastError());
+        uint32_t scored = 0;  // centroids already folded into d_dist
+        while (nc < kmax) {
+            for (; scored < nc; ++scored) {
+                HIP_TRY(hipMemcpyAsync(d_cent, cent.data() + (size_t)scored * dsub, sizeof(float) * dsub, hipMemcpyHostToDevice, c->stream));
+                hipLaunchKernelGGL(pq_seed_distance_kernel, dim3((nn + 255) / 256), dim3(256), 0, c->stream, d_v, nn, dim, off, dsub,
+                                   d_cent, d_dist);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(c->stream));  // d_cent is reused by the next copy
+            }
+            HIP_TRY(hipMemcpyAsync(dist.data(), d_dist, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            float total = -0.0f;
+            for (uint64_t i = 0; i < n; ++i) total = total + dist[i];
+            if (total <= 0.0f) {  // every row equals a chosen centroid: take one that does not, if any
+                std::vector<uint64_t> rem;
+                for (uint64_t i = 0; i < n; ++i) {
+                    bool at = false;
+                    for (uint32_t j = 0; j < nc && !at; ++j) at = memcmp(sub(i, s), cent.data() + (size_t)j * dsub, sizeof(float) * dsub) == 0;
+                    if (!at) rem.push_back(i);
+                }
+                if (rem.empty()) break;
+                memcpy(cent.data() + (size_t)nc * dsub, sub(rem[splitmix64(rs) % rem.size()], s), sizeof(float) * dsub);
+                ++nc;
+                continue;
+            }
+            const float r = rng_unit(rs);
+            float cum = 0.0f;
+            for (uint64_t i = 0; i < n; ++i) {
+                const float w = dist[i] / total;
+                cum = cum + w;
+                if (cum >= r) {
+                    memcpy(cent.data() + (size_t)nc * dsub, sub(i, s), sizeof(float) * dsub);
+                    ++nc;
+                    break;
+                }
+            }
+            // rounding can leave cum < r after the walk: draw again, as the reference's loop does
+        }
+        const uint32_t k = nc;
+        // ---- Lloyd iterations, quantization.rs:639-708 ----
+        std::fill(assign.begin(), assign.end(), 0u);
+        for (uint32_t it = 0; it < iterations; ++it) {
+            HIP_TRY(hipMemcpyAsync(d_cent, cent.data(), (size_t)k * dsub * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(pq_assign_kernel, dim3((nn + 255) / 256), dim3(256), (size_t)k * dsub * sizeof(float), c->stream, d_v, nn,
+                               dim, off, dsub, d_cent, k, d_assign);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(fresh.data(), d_assign, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (fresh == assign) break;
+            assign = fresh;
+            std::fill(offsets.begin(), offsets.end(), 0u);
+            for (uint64_t i = 0; i < n; ++i) offsets[assign[i] + 1] += 1;
+            for (uint32_t j = 0; j < 256; ++j) offsets[j + 1] += offsets[j];
+            {
+                std::vector<uint32_t> at(offsets.begin(), offsets.end() - 1);
+                for (uint64_t i = 0; i < n; ++i) order[at[assign[i]]++] = (uint32_t)i;
+            }
+            HIP_TRY(hipMemcpyAsync(d_order, order.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_off, offsets.data(), 257 * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(pq_centroid_kernel, dim3(k), dim3(64), 0, c->stream, d_v, dim, off, dsub, d_order, d_off, d_newc);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(newc.data(), d_newc, (size_t)k * dsub * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            for (uint32_t j = 0; j < k; ++j)
+                if (offsets[j + 1] == offsets[j]) memcpy(newc.data() + (size_t)j * dsub, sub(splitmix64(rs) % n, s), sizeof(float) * dsub);
+            memcpy(cent.data(), newc.data(), (size_t)k * dsub * sizeof(float));
+        }
+        memcpy(out_books + (size_t)s * 256 * dsub, cent.data(), (size_t)k * dsub * sizeof(float));
+        if (out_ncent) out_ncent[s] = k;
+    }
+    return NEEDLE_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" needle_hip_status needle_hip_pq_train(needle_hip_ctx* c, const float* vectors, uint64_t n, uint32_t dim, uint32_t m,
+                                                 uint32_t iterations, uint64_t seed, float* out_codebooks, uint32_t* out_ncent) {
+    if (!c || !out_codebooks) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0 || !vectors) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "Empty training data");
+    if (dim == 0 || m == 0 || dim % m != 0)
+        return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "dim (%u) must be divisible by the subvector count (%u)", dim, m);
+    if (dim / m > 64) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "sub-vectors of %u dimensions do not fit the on-chip codebook", dim / m);
+    if (n > 0x7fffffffull) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "too many training rows");
+    try {
+        return pq_train_impl(c, vectors, n, dim, m, iterations, seed, out_codebooks, out_ncent);
+    } catch (const std::bad_alloc&) {
+        return fail(NEEDLE_HIP_ERR_OUT_OF_MEMORY, "host allocation failed");
+    }
+}
+
+extern "C" needle_hip_status needle_hip_pq_encode(needle_hip_ctx* c, const float* codebooks, uint32_t dim, uint32_t m,
+                                                  const uint32_t* ncent, const float* vectors, uint64_t n, uint8_t* out_codes) {
+    if (!c) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return NEEDLE_HIP_OK;
+    if (!codebooks || !vectors || !out_codes) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (dim == 0 || m == 0 || dim % m != 0)
+        return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "dim (%u) must be divisible by the subvector count (%u)", dim, m);
+    if (dim / m > 64) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "sub-vectors of %u dimensions do not fit the on-chip codebook", dim / m);
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t B = 1u << 20;  // rows per upload
+    const uint32_t dsub = dim / m;
+    HIP_TRY(c->scratch[0].ensure((size_t)std::min<uint64_t>(B, n) * dim * sizeof(float)));
+    HIP_TRY(c->scratch[1].ensure((size_t)m * 256 * dsub * sizeof(float)));
+    HIP_TRY(c->scratch[2].ensure((size_t)std::min<uint64_t>(B, n) * m));
+    HIP_TRY(c->scratch[3].ensure((size_t)m * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpyAsync(c->scratch[1].p, codebooks, (size_t)m * 256 * dsub * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (ncent) HIP_TRY(hipMemcpyAsync(c->scratch[3].p, ncent, (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    for (uint64_t i0 = 0; i0 < n; i0 += B) {
+        const uint32_t b = (uint32_t)std::min<uint64_t>(B, n - i0);
+        HIP_TRY(hipMemcpyAsync(c->scratch[0].p, vectors + i0 * dim, (size_t)b * dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(launch_pq_encode(c->scratch[0].as<float>(), b, dim, m, c->scratch[1].as<float>(),
+                                 ncent ? c->scratch[3].as<uint32_t>() : nullptr, c->scratch[2].as<uint8_t>(), c->stream));
+        HIP_TRY(hipMemcpyAsync(out_codes + i0 * m, c->scratch[2].p, (size_t)b * m, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return NEEDLE_HIP_OK;
+}

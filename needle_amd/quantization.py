@@ -102,6 +102,30 @@ class ProductQuantizer:
                 books[s, c.shape[0]:] = c[-1]
         return cls(books)
 
+    @classmethod
+    def train_device(cls, ctx: Context, vectors, num_subvectors: int, seed: int = 1, iterations: int = 20) -> "ProductQuantizer":
+        """The same training on the GPU (needle_hip_pq_train): seeded splitmix64 draws, the reference's arithmetic."""
+        v = _f32(vectors)
+        n, dim = v.shape
+        books = np.zeros((num_subvectors, 256, dim // num_subvectors), dtype=F)
+        ncent = np.zeros(num_subvectors, dtype=np.uint32)
+        _lib.check(_lib.lib().needle_hip_pq_train(ctx._h, v.ctypes.data, n, dim, num_subvectors, iterations, seed,
+                                                  books.ctypes.data, ncent.ctypes.data))
+        pq = cls(books)
+        pq.centroids_per_subspace = ncent
+        for s in range(num_subvectors):  # unused codes repeat the last centroid (never the first minimum)
+            if 0 < ncent[s] < 256:
+                pq.codebooks[s, ncent[s]:] = pq.codebooks[s, ncent[s] - 1]
+        return pq
+
+    def encode_device(self, ctx: Context, vectors) -> np.ndarray:
+        """encode() on the GPU (needle_hip_pq_encode)."""
+        v = _f32(vectors)
+        out = np.zeros((v.shape[0], self.num_subvectors), dtype=np.uint8)
+        _lib.check(_lib.lib().needle_hip_pq_encode(ctx._h, self.codebooks.ctypes.data, self.dimensions, self.num_subvectors,
+                                                   None, v.ctypes.data, v.shape[0], out.ctypes.data))
+        return out
+
     def encode(self, vectors) -> np.ndarray:
         """quantization.rs:390-446: per subspace the FIRST centroid at minimum squared distance."""
         v = _f32(vectors)

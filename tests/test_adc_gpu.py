@@ -171,3 +171,27 @@ def test_binary_masks_ties_and_edges(ctx, oracle):
     small = BinaryIndex(ctx, bq, codes[:5])
     _cmp(small.search(queries, 10), obq.batch_search(queries, codes[:5], 10))  # k > n
     small.close()
+
+
+@pytest.mark.parametrize("shape", [(3000, 32, 4), (5000, 96, 12), (200, 24, 3), (1500, 30, 2)])
+def test_pq_training_and_encoding_on_the_device(ctx, oracle, shape):
+    """needle_hip_pq_train / needle_hip_pq_encode against the oracle's seeded restatement of
+    ProductQuantizer::{train, encode} (quantization.rs:330-446, kmeans :597-711): same draws -> bit-equal
+    codebooks; codes equal for every row."""
+    from needle_amd.quantization import ProductQuantizer
+
+    n, dim, m = shape
+    rng = np.random.default_rng(n + m)
+    data = rng.standard_normal((n, dim)).astype(F)
+    data[40:70] = data[3]  # repeated rows: zero seeding weights, possible empty clusters
+    for seed in (1, 99):
+        opq = oracle.ProductQuantizer.train(data, m, seed=seed)
+        pq = ProductQuantizer.train_device(ctx, data, m, seed=seed)
+        assert np.array_equal(pq.centroids_per_subspace, opq.ncent)
+        for s in range(m):
+            k = int(opq.ncent[s])
+            assert np.array_equal(pq.codebooks[s, :k].view(np.uint32), opq.codebooks[s, :k].view(np.uint32)), s
+    probe = rng.standard_normal((777, dim)).astype(F)
+    want = opq.encode(probe)
+    assert np.array_equal(pq.encode_device(ctx, probe), want)
+    assert np.array_equal(pq.encode(probe[:100]), want[:100])

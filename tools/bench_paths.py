@@ -223,6 +223,15 @@ def pq_case(ctx, dev, n, dim, m_sub, nq, k, steps, oracle=None):
         extra["parity"] = {"queries_checked": s, "rows": ns, "ids_equal": bool(np.array_equal(gi, oi)),
                            "dists_bit_equal": bool(np.array_equal(bits(gd), bits(od)))}
         small.close()
+    # codebook training and encoding on the device (Gaussian rows; the scan above uses random codes and books)
+    sample = rng.standard_normal((65536, dim), dtype=F)
+    t0 = time.perf_counter()
+    tpq = na.quantization.ProductQuantizer.train_device(ctx, sample, m_sub, seed=5)
+    extra["train_s_65536_rows"] = round(time.perf_counter() - t0, 2)
+    rows = rng.standard_normal((min(n, 1_000_000), dim), dtype=F)
+    t0 = time.perf_counter()
+    tpq.encode_device(ctx, rows)
+    extra["encode_rows_per_s_incl_pcie"] = round(rows.shape[0] / (time.perf_counter() - t0), 1)
     emit("pq", f"PQ m={m_sub} table scan over {n}x{m_sub} codes (dim {dim}), k={k}", nq, sec, extra)
     ix.close()
 
