@@ -468,7 +468,9 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     if (precision == NEEDLE_PRECISION_BF16 && flat_scan_bf16_dpad(ix->dim) == 0) precision = NEEDLE_PRECISION_FP32;
     if (precision == NEEDLE_PRECISION_BF16 && choose_kprime(std::min(k, n), precision) > KPRIME_MAX)
         precision = NEEDLE_PRECISION_FP32;
-    const uint32_t kprime = choose_kprime(std::min(k, n), precision);
+    uint32_t kprime = choose_kprime(std::min(k, n), precision);
+    // bf16: an index whose earlier batches left many queries undecided keeps more candidates per query (see below)
+    if (precision == NEEDLE_PRECISION_BF16) kprime = std::min<uint32_t>(round_up(kprime + ix->bf16_extra_slack, 16), KPRIME_MAX);
     const bool exact_only = precision == NEEDLE_PRECISION_EXACT_SCAN || (!sq8 && !metric_has_first_pass(ix->metric)) ||
                             kprime > KPRIME_MAX;
     if (exact_only) {
@@ -681,6 +683,12 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
         c->m.scan_ms_total += ms;
         c->m.last_scan_ms = ms;
     }
+    // The rows a bf16 score cannot tell apart from the k-th hit must all be among the candidates kept.  How many
+    // there are depends on the data (wide, unnormalised rows at large k: dozens), so the slack adapts: a batch that
+    // left more than 2 % of its queries undecided doubles it for the batches that follow.  Only the cost moves; the
+    // hits are proven either way.
+    if (bf16 && q >= 32 && (uint64_t)n_flagged * 50 > q && kprime < (uint32_t)KPRIME_MAX)
+        ix->bf16_extra_slack = std::min<uint32_t>(ix->bf16_extra_slack ? ix->bf16_extra_slack * 2 : 48, KPRIME_MAX);
     if (n_flagged > 0) {
         if (n_flagged > q) n_flagged = q;
         // The exact scan streams the base once per 4 queries: cheaper than another first pass for a handful of

@@ -83,6 +83,7 @@ struct needle_hip_index {
     float* d_norms = nullptr;      // [n_pad]
     uint32_t* d_valid = nullptr;   // live-row bitmask (by row id) or null
     float max_norm = 0.0f;
+    uint32_t bf16_extra_slack = 0; // candidates kept per query beyond the default bf16 slack (grows when batches leave queries undecided)
     float bf16_err = 0.0f;         // max over rows of |row operand - its bf16 copy| (set with d_op_bf16); SQ8: max |code vector|
     std::mutex mu;
     // IVF
