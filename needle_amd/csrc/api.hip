@@ -167,7 +167,7 @@ void nh::index_free(needle_hip_index* ix) {
     for (DevBuf* b : {&ix->w_qraw, &ix->w_qop, &ix->w_qn2, &ix->w_lists, &ix->w_lcnt, &ix->w_cand, &ix->w_candn,
                       &ix->w_tau, &ix->w_flagged, &ix->w_flagcnt, &ix->w_filter, &ix->w_premax, &ix->w_tau0, &ix->x_keys, &ix->x_u32,
                       &ix->x_u64, &ix->x_sel, &ix->x_mask, &ix->v_probe_ids, &ix->v_probe_d, &ix->v_probe_n, &ix->v_probe32,
-                      &ix->v_items, &ix->v_itemq, &ix->v_lbase, &ix->w_qerr, &ix->r_idx, &ix->r_q, &ix->r_ids, &ix->r_dists, &ix->r_cnt, &ix->v_regroup, &ix->b_work})
+                      &ix->v_items, &ix->v_itemq, &ix->v_lbase, &ix->w_qerr, &ix->r_idx, &ix->r_q, &ix->r_ids, &ix->r_dists, &ix->r_cnt, &ix->v_regroup, &ix->b_work, &ix->w_cinit})
         b->release();
     delete ix;
 }
@@ -541,6 +541,16 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     sp.cinit = ix->d_cinit;
     sp.valid = ix->d_valid;
     sp.filter = d_filter;
+    if (!dense && (ix->d_valid || d_filter)) {
+        // Row masks are folded into the accumulator seeds: a dead row starts at -inf and can never pass a threshold, so
+        // the scan does no mask lookup per listed row (a dependent load it cannot hide with one wave per SIMD) and its
+        // wave-level early-out is not defeated by dead rows scoring above the threshold.
+        HIP_TRY(ix->w_cinit.ensure((size_t)ix->n_pad * sizeof(float)));
+        HIP_TRY(launch_masked_seed(ix->d_cinit, ix->d_valid, d_filter, n, ix->n_pad, ix->w_cinit.as<float>(), c->stream));
+        sp.cinit = ix->w_cinit.as<float>();
+        sp.valid = nullptr;
+        sp.filter = nullptr;
+    }
     sp.lists = ix->w_lists.as<uint2>();
     sp.list_counts = ix->w_lcnt.as<uint32_t>();
     sp.n = n;

@@ -185,6 +185,9 @@ hipError_t launch_scatter_results(const uint32_t* d_idx, uint32_t n, uint32_t k,
                                   const uint32_t* d_counts, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
                                   hipStream_t stream);
 
+// per-search accumulator seeds with dead rows (deleted, filtered out, beyond n) at -inf (prep.hip)
+hipError_t launch_masked_seed(const float* d_seed, const uint32_t* d_valid, const uint32_t* d_filter, uint32_t n, uint32_t n_pad,
+                              float* d_out, hipStream_t stream);
 hipError_t launch_fill_empty(uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, uint32_t q,
                              uint32_t k, hipStream_t stream);
 

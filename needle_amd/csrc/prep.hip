@@ -180,4 +180,24 @@ hipError_t launch_validate_rows(const float* d_rows, uint64_t n, uint32_t dim, u
     return hipGetLastError();
 }
 
+// Accumulator seeds of one search under row masks: a row that is deleted, filtered out or beyond n gets -inf, so
+// its first-pass score is -inf and it never passes a threshold -- the scan itself then runs without mask lookups.
+__global__ __launch_bounds__(256) void masked_seed_kernel(const float* __restrict__ seed, const uint32_t* __restrict__ valid,
+                                                          const uint32_t* __restrict__ filter, uint32_t n, uint32_t n_pad,
+                                                          float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pad) return;
+    bool live = i < n;
+    if (live && valid) live = bit_set(valid, i);
+    if (live && filter) live = bit_set(filter, i);
+    out[i] = live ? (seed ? seed[i] : 0.0f) : -INFINITY;
+}
+
+hipError_t launch_masked_seed(const float* d_seed, const uint32_t* d_valid, const uint32_t* d_filter, uint32_t n, uint32_t n_pad,
+                              float* d_out, hipStream_t stream) {
+    if (n_pad == 0) return hipSuccess;
+    hipLaunchKernelGGL(masked_seed_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, stream, d_seed, d_valid, d_filter, n, n_pad, d_out);
+    return hipGetLastError();
+}
+
 }  // namespace nh
