@@ -44,6 +44,20 @@ __global__ void ivf_pad_seed_kernel(const uint32_t* __restrict__ pos2id, uint32_
     if (i < n_pos && pos2id[i] == 0xffffffffu) cinit[i] = -INFINITY;
 }
 
+// Per-search accumulator seeds under row masks: positions whose row is deleted or filtered out get -inf as well, so
+// the list scan runs without any position -> id -> mask lookups.
+__global__ void ivf_masked_seed_kernel(const float* __restrict__ cinit, const uint32_t* __restrict__ pos2id, uint32_t n_pos,
+                                       const uint32_t* __restrict__ valid, const uint32_t* __restrict__ filter,
+                                       float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pos) return;
+    const uint32_t id = pos2id[i];
+    bool live = id != 0xffffffffu;
+    if (live && valid) live = nh::bit_set(valid, id);
+    if (live && filter) live = nh::bit_set(filter, id);
+    out[i] = live ? cinit[i] : -INFINITY;
+}
+
 __global__ void ivf_narrow_probe_kernel(const uint64_t* __restrict__ ids, uint32_t total, uint32_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) out[i] = (uint32_t)ids[i];  // padding UINT64_MAX -> UINT32_MAX
@@ -514,8 +528,15 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     sp.base_op = bf16 ? (const void*)ix->d_op_bf16 : (const void*)ix->d_op_f32;
     sp.query_op = ix->w_qop.p;
     sp.cinit = ix->d_cinit;
-    sp.valid = ix->d_valid;
-    sp.filter = d_filter;
+    if (ix->d_valid || d_filter) {
+        HIP_TRY(ix->w_cinit.ensure((size_t)ix->n_pad * sizeof(float)));
+        hipLaunchKernelGGL(ivf_masked_seed_kernel, dim3((ix->n_pad + 255) / 256), dim3(256), 0, c->stream, ix->d_cinit, ix->d_pos2id,
+                           ix->n_pad, ix->d_valid, d_filter, ix->w_cinit.as<float>());
+        HIP_TRY(hipGetLastError());
+        sp.cinit = ix->w_cinit.as<float>();
+    }
+    sp.valid = nullptr;  // dead rows and padding positions carry -inf seeds: the scan needs no mask
+    sp.filter = nullptr;
     sp.lists = ix->w_lists.as<uint2>();
     sp.list_counts = ix->w_lcnt.as<uint32_t>();
     sp.n = ix->n_pad;

@@ -193,3 +193,37 @@ def test_training_matches_the_seeded_cpu_kmeans(ctx, oracle, shape):
     with pytest.raises(ValueError):
         ix.train(np.zeros((0, d), dtype=F))
     ix.close()
+
+
+def test_ivf_under_row_masks(ctx, oracle):
+    """Deleted rows (valid mask) and a search-time filter: the lists the oracle scans hold the live rows only."""
+    import ctypes as C
+
+    from needle_amd import _lib
+    from needle_amd.index import _mask_words
+
+    n, d, nlist, nprobe, k = 30000, 48, 32, 6, 10
+    base, cents, ix, assign, _, _ = _setup(oracle, ctx, n, d, nlist, nprobe, seed=77, kind="gauss")
+    rng = np.random.default_rng(5)
+    valid = rng.random(n) > 0.3
+    filt = rng.random(n) < 0.2
+    queries = rng.standard_normal((150, d)).astype(F)
+
+    def lists_of(live):
+        rows = np.flatnonzero(live)
+        order = rows[np.argsort(assign[rows], kind="stable")].astype(np.uint64)
+        offsets = np.zeros(nlist + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum(np.bincount(assign[rows], minlength=nlist))
+        return offsets, order
+
+    h = ix._resident()
+    vm = _mask_words(valid, n)
+    _lib.check(_lib.lib().needle_hip_index_set_valid_mask(h, vm.ctypes.data))
+    for precision in ("fp32", "bf16"):
+        off, order = lists_of(valid)
+        _check_search(oracle, ix, base, cents, off, order, queries, nprobe, k, precision=precision)
+        off, order = lists_of(valid & filt)
+        _check_search(oracle, ix, base, cents, off, order, queries, nprobe, k, precision=precision, filter_mask=filt)
+    ids, _, counts = ix.batch_search_arrays(queries, k, filter_mask=np.zeros(n, dtype=bool))
+    assert counts.tolist() == [0] * 150
+    ix.close()
