@@ -437,10 +437,29 @@ needle_hip_status nh::ensure_bf16_copy(needle_hip_index* ix) {
     uint16_t* d = nullptr;
     uint32_t* d_bits = nullptr;
     HIP_TRY(hipMalloc((void**)&d, bytes));
-    hipError_t e = hipMalloc((void**)&d_bits, sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemsetAsync(d_bits, 0, sizeof(uint32_t), c->stream);
+    hipError_t e = hipMalloc((void**)&d_bits, 2 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(d_bits, 0, 2 * sizeof(uint32_t), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d, 0, bytes, c->stream);
-    const bool sq8 = ix->kind == KIND_SQ8;
+    const bool sq8 = ix->kind == KIND_SQ8, pq = ix->kind == KIND_PQ;
+    if (e == hipSuccess && pq) {
+        // the decoded rows are the operand: score = q.row - |row|^2/2, as a Euclidean flat index over them
+        if (!ix->d_cinit) {
+            e = hipMalloc((void**)&ix->d_cinit, (size_t)ix->n_pad * sizeof(float));
+            if (e == hipSuccess) e = hipMemsetAsync(ix->d_cinit, 0, (size_t)ix->n_pad * sizeof(float), c->stream);
+        }
+        if (e == hipSuccess)
+            e = launch_pq_decode_bf16(ix->d_codes, ix->d_codebooks, ix->n, ix->pq_m, ix->pq_dsub, ix->dpad_bf16, d, ix->d_cinit,
+                                      d_bits, c->stream);
+        uint32_t two[2] = {0, 0};
+        if (e == hipSuccess) e = hipMemcpyAsync(two, d_bits, sizeof(two), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (d_bits) (void)hipFree(d_bits);
+        if (e != hipSuccess) { (void)hipFree(d); HIP_TRY(e); }
+        memcpy(&ix->max_norm, &two[0], sizeof(float));
+        memcpy(&ix->bf16_err, &two[1], sizeof(float));
+        ix->d_op_bf16 = d;
+        return NEEDLE_HIP_OK;
+    }
     if (e == hipSuccess && sq8)  // codes are exact in bf16; ix->bf16_err already holds max |code vector|
         e = launch_sq8_codes_bf16(ix->d_codes, ix->n, ix->dim, ix->dpad_f32, ix->dpad_bf16, d, c->stream);
     else if (e == hipSuccess)
@@ -666,6 +685,9 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     pp.max_norm = ix->max_norm;
     pp.qerr = (bf16 && !sq8) ? ix->w_qerr.as<float>() : nullptr;
     pp.berr = ix->bf16_err;
+    if (ix->kind == KIND_PQ) {  // candidates are re-scored with the distance-table arithmetic
+        pp.pq_codes = ix->d_codes; pp.pq_books = ix->d_codebooks; pp.pq_m = ix->pq_m; pp.pq_dsub = ix->pq_dsub;
+    }
     if (sq8) {
         pp.sq_codes = ix->d_codes; pp.sq_min = ix->d_sq_min; pp.sq_scale = ix->d_sq_scale; pp.sq_stride = ix->dpad_f32;
         pp.aux_norm = (float)(ix->sq_min_norm * (1.0 + 1e-6));
@@ -704,6 +726,24 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
         // The exact scan streams the base once per 4 queries: cheaper than another first pass for a handful of
         // queries, or for any number of them over a small base (an IVF centroid set).
         const bool few = n_flagged <= 16 || (uint64_t)n_flagged * ix->n_pad <= (4ull << 20);
+        if (ix->kind == KIND_PQ) {
+            // product-quantized rows: the undecided queries take the distance-table scan, which is exact by itself
+            HIP_TRY(ix->r_idx.ensure((size_t)n_flagged * sizeof(uint32_t)));
+            HIP_TRY(ix->r_q.ensure((size_t)n_flagged * ix->dim * sizeof(float)));
+            HIP_TRY(ix->r_ids.ensure((size_t)n_flagged * k * sizeof(uint64_t)));
+            HIP_TRY(ix->r_dists.ensure((size_t)n_flagged * k * sizeof(float)));
+            HIP_TRY(ix->r_cnt.ensure((size_t)n_flagged * sizeof(uint32_t)));
+            HIP_TRY(hipMemcpyAsync(ix->r_idx.p, pp.flagged, (size_t)n_flagged * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(launch_gather_rows(d_queries, ix->r_idx.as<uint32_t>(), n_flagged, ix->dim, ix->r_q.as<float>(), c->stream));
+            ST_TRY(pq_search_batch_device(ix, ix->r_q.as<float>(), n_flagged, k, d_filter, ix->r_ids.as<uint64_t>(),
+                                          ix->r_dists.as<float>(), ix->r_cnt.as<uint32_t>()));
+            HIP_TRY(launch_scatter_results(ix->r_idx.as<uint32_t>(), n_flagged, k, ix->r_ids.as<uint64_t>(), ix->r_dists.as<float>(),
+                                           ix->r_cnt.as<uint32_t>(), d_out_ids, d_out_dists, d_out_counts, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            std::lock_guard<std::mutex> g(c->mu);
+            c->m.fallback_queries += n_flagged;
+            return NEEDLE_HIP_OK;
+        }
         if (bf16 && !few) {
             // The bf16 scores could not separate these queries' k-th hit from the rows left out: give them
             // the fp32 first pass (whose own leftovers go to the exact scan) and put the answers in place.
@@ -752,7 +792,11 @@ static needle_hip_status search_device_locked(needle_hip_index* ix, const float*
         const uint32_t QB = 16384;
         for (uint32_t q0 = 0; q0 < q; q0 += QB) {
             const uint32_t qb = std::min(QB, q - q0);
-            if (ix->kind == KIND_PQ)
+            // product-quantized rows: precision bf16 scores the decoded rows on the matrix cores and re-scores the
+            // candidates with the distance-table arithmetic; otherwise the table scan itself
+            const bool pq_mfma = ix->kind == KIND_PQ && precision == NEEDLE_PRECISION_BF16 && flat_scan_bf16_dpad(ix->dim) != 0 &&
+                                 choose_kprime((uint32_t)std::min<uint64_t>(k, ix->n), NEEDLE_PRECISION_BF16) <= (uint32_t)KPRIME_MAX;
+            if (ix->kind == KIND_PQ && !pq_mfma)
                 ST_TRY(pq_search_batch_device(ix, d_queries + (size_t)q0 * ix->dim, qb, k, d_filter,
                                               d_out_ids + (size_t)q0 * k, d_out_dists + (size_t)q0 * k,
                                               d_out_counts + q0));

@@ -21,8 +21,9 @@ extern "C" needle_hip_status needle_hip_pq_build(needle_hip_ctx* c, const uint8_
     ix->kind = KIND_PQ;
     ix->n = n;
     ix->dim = dim;
-    ix->n_pad = (uint32_t)n;
+    ix->n_pad = round_up((uint32_t)n, TILE_ROWS);  // rows of the decoded bf16 operand, built on the first bf16 search
     ix->metric = NEEDLE_METRIC_EUCLIDEAN;
+    ix->arith = NEEDLE_ARITH_DISTANCE_RS;
     ix->pq_m = m;
     ix->pq_dsub = dim / m;
     const size_t cb_bytes = (size_t)m * 256 * ix->pq_dsub * sizeof(float);

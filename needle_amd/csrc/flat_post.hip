@@ -421,7 +421,11 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams
         id = p.pos2id ? p.pos2id[pos] : pos;
     }
     if (j < KPRIME_MAX) spos[j] = pos;
-    if (p.sq_codes) {
+    if (p.pq_codes) {
+        if (j < nc)
+            d = canon_distance(exact_pq(p.query_raw + (uint64_t)q * p.dim, p.pq_codes + (uint64_t)pos * p.pq_m, p.pq_books, p.pq_m,
+                                        p.pq_dsub));
+    } else if (p.sq_codes) {
         if (j < nc)
             d = canon_distance(exact_sq8(p.query_raw + (uint64_t)q * p.dim, p.sq_codes + (uint64_t)pos * p.sq_stride,
                                          p.sq_min, p.sq_scale, p.dim));

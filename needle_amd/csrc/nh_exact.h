@@ -129,6 +129,22 @@ __device__ inline float exact_sq8(const float* __restrict__ q, const uint8_t* __
     return sqrtf(sum);
 }
 
+// ProductQuantizer::{compute_distance_table, distance_with_table}, src/indexing/quantization.rs:468-503: per subspace
+// the sum (from -0.0) of (q - centroid)^2 over its dimensions -- the table entry of the row's code --, the entries
+// summed from +0.0 in subspace order; sqrt.
+__device__ inline float exact_pq(const float* __restrict__ q, const uint8_t* __restrict__ codes,
+                                 const float* __restrict__ codebooks, uint32_t m, uint32_t dsub) {
+    float dist = 0.0f;
+    for (uint32_t s = 0; s < m; ++s) {
+        const float* c = codebooks + ((uint64_t)s * 256 + codes[s]) * dsub;
+        const float* x = q + s * dsub;
+        float t = -0.0f;
+        for (uint32_t j = 0; j < dsub; ++j) { const float d = x[j] - c[j]; const float sq = d * d; t = t + sq; }
+        dist = dist + t;
+    }
+    return sqrtf(dist);
+}
+
 __device__ inline float exact_distance(int metric, int arith, const float* __restrict__ q,
                                        const float* __restrict__ b, uint32_t dim) {
     return arith == NEEDLE_ARITH_ACCEL_CHUNK4 ? exact_chunk4(metric, q, b, dim)

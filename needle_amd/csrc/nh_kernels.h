@@ -66,6 +66,9 @@ hipError_t launch_sq8_query_prep(const float* d_queries, uint32_t q, uint32_t di
                                  const float* d_scale, float* d_qop, uint16_t* d_qop_bf16, double* d_qconst,
                                  double* d_qscaled_err2, hipStream_t stream);
 // bf16 operand copy [n][dpad] of a u8 code matrix [n][stride] (exact); d_out is zero-filled by the caller.
+// decoded PQ rows as the bf16 operand of the matrix-core scan, with -|row|^2/2, max |row| and max rounding error (prep.hip)
+hipError_t launch_pq_decode_bf16(const uint8_t* d_codes, const float* d_books, uint64_t n, uint32_t m, uint32_t dsub, uint32_t dpad,
+                                 uint16_t* d_op_bf16, float* d_cinit, uint32_t* d_max_bits, hipStream_t stream);
 hipError_t launch_sq8_codes_bf16(const uint8_t* d_codes, uint64_t n, uint32_t dim, uint32_t stride, uint32_t dpad,
                                  uint16_t* d_out, hipStream_t stream);
 
@@ -92,6 +95,9 @@ struct PostParams {
     const uint32_t* filter;
     // scalar-quantized rows: distances are ScalarQuantizer::asymmetric_distance on the codes
     const uint8_t* sq_codes;  // [n_pad][sq_stride] or null
+    const uint8_t* pq_codes;  // PQ rows scored through their decoded bf16 copy: [n][pq_m] codes, else null
+    const float* pq_books;    // [pq_m][256][pq_dsub]
+    uint32_t pq_m, pq_dsub;
     const float* sq_min;      // [dim]
     const float* sq_scale;    // [dim]
     uint32_t sq_stride;

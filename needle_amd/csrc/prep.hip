@@ -180,6 +180,43 @@ hipError_t launch_validate_rows(const float* d_rows, uint64_t n, uint32_t dim, u
     return hipGetLastError();
 }
 
+// ---- product-quantized rows as a matrix-core operand ------------------------------------------------------------
+// The decoded row (concatenation of the centroids its codes select) rounded to bf16; cinit = -|row|^2 / 2;
+// max_bits[0] = max |row| and max_bits[1] = max |row - bf16(row)|, both rounded up.  One wave per row.
+__global__ __launch_bounds__(256) void pq_decode_bf16_kernel(const uint8_t* __restrict__ codes, const float* __restrict__ books,
+                                                             uint64_t n, uint32_t m, uint32_t dsub, uint32_t dpad,
+                                                             uint16_t* __restrict__ op, float* __restrict__ cinit,
+                                                             uint32_t* __restrict__ max_bits) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t row = (uint64_t)blockIdx.x * 4 + wave;
+    if (row >= n) return;
+    const uint32_t dim = m * dsub;
+    double s = 0.0, err = 0.0;
+    for (uint32_t i = lane; i < dim; i += 64) {
+        const uint32_t sub = i / dsub, j = i % dsub;
+        const float v = books[((uint64_t)sub * 256 + codes[row * m + sub]) * dsub + j];
+        const uint16_t b = bf16_rne(v);
+        op[row * dpad + i] = b;
+        const double e = (double)v - (double)__uint_as_float((uint32_t)b << 16);
+        s += (double)v * (double)v;
+        err += e * e;
+    }
+    for (int off = 32; off; off >>= 1) { s += __shfl_xor(s, off); err += __shfl_xor(err, off); }
+    if (lane == 0) {
+        cinit[row] = -(float)(0.5 * s);
+        atomicMax(max_bits, __float_as_uint((float)sqrt(s)) + 1u);
+        atomicMax(max_bits + 1, __float_as_uint((float)sqrt(err)) + 2u);
+    }
+}
+
+hipError_t launch_pq_decode_bf16(const uint8_t* d_codes, const float* d_books, uint64_t n, uint32_t m, uint32_t dsub, uint32_t dpad,
+                                 uint16_t* d_op_bf16, float* d_cinit, uint32_t* d_max_bits, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pq_decode_bf16_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, stream, d_codes, d_books, n, m, dsub, dpad,
+                       d_op_bf16, d_cinit, d_max_bits);
+    return hipGetLastError();
+}
+
 // Accumulator seeds of one search under row masks: a row that is deleted, filtered out or beyond n gets -inf, so
 // its first-pass score is -inf and it never passes a threshold -- the scan itself then runs without mask lookups.
 __global__ __launch_bounds__(256) void masked_seed_kernel(const float* __restrict__ seed, const uint32_t* __restrict__ valid,

@@ -42,7 +42,9 @@ def test_pq_table_scan(ctx, oracle, shape):
     assert np.array_equal(pq.encode(base[:200]), codes[:200])  # host mirror of encode == oracle
     queries = rng.standard_normal((37, dim)).astype(F)
     ix = PqIndex(ctx, pq, codes)
-    _cmp(ix.search(queries, k), opq.batch_search(queries, codes, k))
+    want = opq.batch_search(queries, codes, k)
+    _cmp(ix.search(queries, k), want)
+    _cmp(ix.search(queries, k, precision="bf16"), want)  # decoded rows on the matrix cores, table arithmetic for the hits
     # the scanned distance equals distance_with_table AND asymmetric_distance within 1e-5 (quantization.rs:1053-1081)
     ids, d, _ = ix.search(queries[:2], 3)
     for qi in range(2):
@@ -68,11 +70,15 @@ def test_pq_masks_ties_and_edges(ctx, oracle):
     _cmp(ix.search(queries, 12), opq.batch_search(queries, codes, 12, valid=valid))
     _cmp(ix.search(queries, 12, filter_mask=filt), opq.batch_search(queries, codes, 12, valid=valid & filt))
     _cmp(ix.search(queries, 256), opq.batch_search(queries, codes, 256, valid=valid))
+    for kk in (12, 100, 256):  # bf16: the block of identical codes ties at the top; k = 256 exceeds the candidate budget -> table scan
+        _cmp(ix.search(queries, kk, precision="bf16"), opq.batch_search(queries, codes, kk, valid=valid))
+    _cmp(ix.search(queries, 12, precision="bf16", filter_mask=filt), opq.batch_search(queries, codes, 12, valid=valid & filt))
     ids, _, counts = ix.search(queries, 0)
     assert ids.shape == (10, 0) and counts.tolist() == [0] * 10
     ix.close()
     small = PqIndex(ctx, ProductQuantizer(opq.codebooks), codes[:5])
     _cmp(small.search(queries, 10), opq.batch_search(queries, codes[:5], 10))  # k > n
+    _cmp(small.search(queries, 10, precision="bf16"), opq.batch_search(queries, codes[:5], 10))
     small.close()
 
 

@@ -207,33 +207,48 @@ def pq_case(ctx, dev, n, dim, m_sub, nq, k, steps, oracle=None):
     queries = rng.standard_normal((nq, dim), dtype=F)
     ix = na.quantization.PqIndex(ctx, pq, codes)
     dq = torch.from_numpy(queries).to(dev)
-    sec, out = timed(lambda: search_device(ix._h, dq, k), steps, 1)
-    qg = min(3, (150 * 1024) // (m_sub * 1024))
-    groups = -(-nq // qg)
-    byts = groups * n * m_sub  # every query group streams the code matrix once
-    extra = {"queries_per_workgroup": qg, "bytes_scanned": byts, "GBps_over_whole_search": round(byts / sec / 1e9, 1),
-             "frac_of_hbm_peak": round(byts / sec / 1e9 / HBM_PEAK_GBS, 4),
-             "table_lookups_per_s": round(nq * n * m_sub / sec / 1e12, 3)}
-    if oracle is not None:
-        s, ns = 6, 500_000
-        small = na.quantization.PqIndex(ctx, pq, codes[:ns])
-        gi, gd, gc = small.search(queries[:s], k)
-        opq = oracle.ProductQuantizer(books, np.full(m_sub, 256, dtype=np.uint32), dim, m_sub)
-        oi, od, oc = opq.batch_search(queries[:s], codes[:ns], k)
-        extra["parity"] = {"queries_checked": s, "rows": ns, "ids_equal": bool(np.array_equal(gi, oi)),
-                           "dists_bit_equal": bool(np.array_equal(bits(gd), bits(od)))}
-        small.close()
-    # codebook training and encoding on the device (Gaussian rows; the scan above uses random codes and books)
+    for prec in ("bf16", "fp32"):
+        ctx.set_profiling(True)
+        ctx.reset_metrics()
+        sec, out = timed(lambda: search_device(ix._h, dq, k, precision=prec), steps, 1)
+        mm = ctx.metrics()
+        ctx.set_profiling(False)
+        scan_ms = mm["scan_ms_total"] / max(mm["scan_launches"], 1)
+        if prec == "bf16":  # the decoded rows (bf16, dim values each) stream once per 256-query block
+            byts = (-(-nq // 256)) * n * dim * 2
+            extra = {"first_pass": "bf16 decoded rows on the matrix cores, table arithmetic for the candidates",
+                     "scan_ms": round(scan_ms, 3), "bytes_scanned": byts, "scan_GBps": round(byts / scan_ms / 1e6, 1),
+                     "frac_of_hbm_peak": round(byts / scan_ms / 1e6 / HBM_PEAK_GBS, 4),
+                     "scan_tflops": round(2.0 * nq * n * dim / scan_ms / 1e9, 1),
+                     "fallback_per_batch": mm["fallback_queries"] / (steps + 1)}
+        else:
+            qg = min(3, (150 * 1024) // (m_sub * 1024))
+            byts = (-(-nq // qg)) * n * m_sub  # every query group streams the code matrix once
+            extra = {"first_pass": "f32 distance-table scan", "queries_per_workgroup": qg, "bytes_scanned": byts,
+                     "GBps_over_whole_search": round(byts / sec / 1e9, 1),
+                     "frac_of_hbm_peak": round(byts / sec / 1e9 / HBM_PEAK_GBS, 4),
+                     "table_lookups_per_s": round(nq * n * m_sub / sec / 1e12, 3)}
+        if oracle is not None:
+            s, ns = 6, 500_000
+            small = na.quantization.PqIndex(ctx, pq, codes[:ns])
+            gi, gd, gc = small.search(queries[:s], k, precision=prec)
+            opq = oracle.ProductQuantizer(books, np.full(m_sub, 256, dtype=np.uint32), dim, m_sub)
+            oi, od, oc = opq.batch_search(queries[:s], codes[:ns], k)
+            extra["parity"] = {"queries_checked": s, "rows": ns, "ids_equal": bool(np.array_equal(gi, oi)),
+                               "dists_bit_equal": bool(np.array_equal(bits(gd), bits(od)))}
+            small.close()
+        emit("pq", f"PQ m={m_sub} asymmetric scan over {n}x{m_sub} codes (dim {dim}), k={k}", nq, sec, extra)
+    ix.close()
+    # codebook training and encoding on the device (Gaussian rows; the scans above use random codes and books)
     sample = rng.standard_normal((65536, dim), dtype=F)
     t0 = time.perf_counter()
     tpq = na.quantization.ProductQuantizer.train_device(ctx, sample, m_sub, seed=5)
-    extra["train_s_65536_rows"] = round(time.perf_counter() - t0, 2)
+    train_s = time.perf_counter() - t0
     rows = rng.standard_normal((min(n, 1_000_000), dim), dtype=F)
     t0 = time.perf_counter()
     tpq.encode_device(ctx, rows)
-    extra["encode_rows_per_s_incl_pcie"] = round(rows.shape[0] / (time.perf_counter() - t0), 1)
-    emit("pq", f"PQ m={m_sub} table scan over {n}x{m_sub} codes (dim {dim}), k={k}", nq, sec, extra)
-    ix.close()
+    print(json.dumps({"path": "pq_build", "train_s_65536_rows": round(train_s, 2),
+                      "encode_rows_per_s_incl_pcie": round(rows.shape[0] / (time.perf_counter() - t0), 1)}), flush=True)
 
 
 def binary_case(ctx, dev, n, dim, nq, k, steps, oracle=None):
