@@ -167,7 +167,7 @@ void nh::index_free(needle_hip_index* ix) {
     for (DevBuf* b : {&ix->w_qraw, &ix->w_qop, &ix->w_qn2, &ix->w_lists, &ix->w_lcnt, &ix->w_cand, &ix->w_candn,
                       &ix->w_tau, &ix->w_flagged, &ix->w_flagcnt, &ix->w_filter, &ix->w_premax, &ix->w_tau0, &ix->x_keys, &ix->x_u32,
                       &ix->x_u64, &ix->x_sel, &ix->x_mask, &ix->v_probe_ids, &ix->v_probe_d, &ix->v_probe_n, &ix->v_probe32,
-                      &ix->v_items, &ix->v_itemq, &ix->v_lbase, &ix->w_qerr, &ix->r_idx, &ix->r_q, &ix->r_ids, &ix->r_dists, &ix->r_cnt, &ix->v_regroup, &ix->b_work, &ix->w_cinit})
+                      &ix->v_items, &ix->v_itemq, &ix->v_lbase, &ix->w_qerr, &ix->r_idx, &ix->r_q, &ix->r_ids, &ix->r_dists, &ix->r_cnt, &ix->v_regroup, &ix->b_work, &ix->w_cinit, &ix->w_cscore})
         b->release();
     delete ix;
 }
@@ -693,6 +693,11 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
         pp.aux_norm = (float)(ix->sq_min_norm * (1.0 + 1e-6));
         if (bf16) pp.qaux = ix->w_qn2.as<double>() + q_pad;
     }
+    const bool prune = !(sp.debug & 16u);
+    if (prune) {
+        HIP_TRY(ix->w_cscore.ensure((size_t)q * kprime * sizeof(float)));
+        pp.cand_scores = ix->w_cscore.as<float>();
+    }
     if (dense) {
         pp.dense_scores = sp.dense_scores;
         pp.dense_ld = sp.dense_ld;
@@ -702,6 +707,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     } else {
         HIP_TRY(launch_merge_select(pp, c->stream));
     }
+    if (prune) HIP_TRY(launch_prune_candidates(pp, band, c->stream));
     HIP_TRY(launch_rescore_finalize(pp, c->stream));
 
     uint32_t n_flagged = 0;

@@ -604,7 +604,10 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     pp.max_norm = ix->max_norm;
     pp.qerr = bf16 ? ix->w_qerr.as<float>() : nullptr;
     pp.berr = ix->bf16_err;
+    HIP_TRY(ix->w_cscore.ensure((size_t)q * kprime * sizeof(float)));
+    pp.cand_scores = ix->w_cscore.as<float>();
     HIP_TRY(launch_merge_select(pp, c->stream));
+    HIP_TRY(launch_prune_candidates(pp, band, c->stream));
     HIP_TRY(launch_rescore_finalize(pp, c->stream));
 
     uint32_t n_flagged = 0;

@@ -227,6 +227,62 @@ hipError_t launch_dense_select(const PostParams& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------
+// prune_candidates: one wave per query, between selection and exact re-scoring.
+// With s_k the k-th largest first-pass score among the candidates and eps the score uncertainty, a candidate scoring
+// below s_k - 2 eps is worse than k other rows whatever the rounding did, so it needs no exact distance.  Dropped
+// candidates become "rows not re-scored": tau_star rises to the best dropped score and the bound check covers them
+// like any other non-candidate.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void prune_candidates_kernel(PostParams p, TauBand band) {
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    const uint32_t nc = min(p.cand_n[q], p.kprime);
+    if (nc <= p.k) return;  // every candidate may be a hit
+    constexpr int PER = (KPRIME_MAX + 63) / 64;
+    uint32_t ord[PER], id[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const uint32_t e = i * 64 + lane;
+        ord[i] = e < nc ? f2ord(p.cand_scores[(uint64_t)q * p.kprime + e]) : 0u;
+        id[i] = e < nc ? p.cand_ids[(uint64_t)q * p.kprime + e] : 0u;
+    }
+    uint32_t kth = 0;  // k-th largest score, bit by bit
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t trial = kth | (1u << bit);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(i * 64 + lane < nc && ord[i] >= trial));
+        if (cnt >= p.k) kth = trial;
+    }
+    const float cut = (float)((double)ord2f(kth) - 2.0 * band_eps(band, q));
+    if (!(cut == cut)) return;
+    const uint32_t cut_ord = f2ord(cut);
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint32_t base = 0, best_dropped = 0;
+    bool any_dropped = false;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const bool in = i * 64 + lane < nc;
+        const bool keep = in && ord[i] >= cut_ord;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) p.cand_ids[(uint64_t)q * p.kprime + base + __builtin_popcountll(m & lt_mask)] = id[i];
+        base += __builtin_popcountll(m);
+        if (in && !keep) { best_dropped = max(best_dropped, ord[i]); any_dropped = true; }
+    }
+    if (__builtin_amdgcn_ballot_w64(any_dropped) == 0) return;
+    for (int off = 32; off; off >>= 1) best_dropped = max(best_dropped, (uint32_t)__shfl_xor((int)best_dropped, off));
+    if (lane == 0) {
+        p.cand_n[q] = base;
+        p.tau_star[q] = fmaxf(p.tau_star[q], ord2f(best_dropped));
+    }
+}
+
+hipError_t launch_prune_candidates(const PostParams& p, const TauBand& band, hipStream_t stream) {
+    if (p.q == 0 || !p.cand_scores) return hipSuccess;
+    hipLaunchKernelGGL(prune_candidates_kernel, dim3(p.q), dim3(64), 0, stream, p, band);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // The bound check.  tau is the first-pass score threshold (larger = closer),
 // dk the exact distance of the k-th hit.  Returns true when no non-candidate
 // row can beat or tie the k-th hit:

@@ -246,13 +246,6 @@ __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
     if (h == 0 && q_live) p.list_counts[list_idx] = cnt;
 }
 
-__device__ inline double band_eps(const TauBand& band, uint32_t q) {
-    if (band.sq8) return score_eps_sq8(band.qn2[q], band.bmax, band.mnorm, band.dim, band.qs2 ? band.qs2[q] : -1.0, band.berr);
-    const double qn = sqrt(band.qn2[q]);
-    const double lowp = bf16_score_err(band.metric, qn, band.bmax, band.qerr ? (double)band.qerr[q] : -1.0, band.berr);
-    return score_eps(band.metric, lowp, qn, band.bmax, band.dim);
-}
-
 // One wave per query, between two launches that share candidate lists: with at least kseed candidates listed,
 // the kseed-th largest listed score is a threshold that kseed live rows reach; the next launch starts from it.
 __global__ __launch_bounds__(64) void tau_refresh_kernel(const uint2* __restrict__ lists, const uint32_t* __restrict__ counts,

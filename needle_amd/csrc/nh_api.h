@@ -107,6 +107,7 @@ struct needle_hip_index {
     // per-search workspace (grow-only)
     nh::DevBuf w_qraw, w_qop, w_qn2, w_lists, w_lcnt, w_cand, w_candn, w_tau, w_flagged, w_flagcnt, w_filter, w_premax,
         w_tau0;
+    nh::DevBuf w_cscore; // [q][kprime] first-pass scores of the selected candidates (pruning before the exact re-score)
     nh::DevBuf w_cinit; // [n_pad] accumulator seeds of a search under row masks (dead rows at -inf)
     nh::DevBuf w_qerr;  // [q_pad] |query operand - its bf16 copy|
     nh::DevBuf r_idx, r_q, r_ids, r_dists, r_cnt;  // queries a reduced-precision pass could not decide, re-run in fp32

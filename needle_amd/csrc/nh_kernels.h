@@ -16,6 +16,21 @@ struct TauBand {
     uint32_t dim;
     int metric, precision, sq8;
 };
+#ifdef __HIPCC__
+// absolute uncertainty of a first-pass score of query q against any row (operand rounding + f32 accumulation)
+__device__ inline double band_eps(const TauBand& band, uint32_t q) {
+    if (band.sq8) return score_eps_sq8(band.qn2[q], band.bmax, band.mnorm, band.dim, band.qs2 ? band.qs2[q] : -1.0, band.berr);
+    const double qn = sqrt(band.qn2[q]);
+    const double lowp = bf16_score_err(band.metric, qn, band.bmax, band.qerr ? (double)band.qerr[q] : -1.0, band.berr);
+    return score_eps(band.metric, lowp, qn, band.bmax, band.dim);
+}
+#endif
+// Between candidate selection and exact re-scoring: candidates whose first-pass score lies more than twice the score
+// uncertainty below the k-th best candidate score cannot be among the k hits; they are dropped (cand_ids / cand_n
+// compacted) and tau_star is raised to the best dropped score, so the bound check still covers them.
+// cand_scores must hold the candidates' first-pass scores.
+struct PostParams;
+hipError_t launch_prune_candidates(const PostParams& p, const TauBand& band, hipStream_t stream);
 // pre-pass over p.pre_tiles tiles per slice (writes p.pre_max), then d_tau0[q_pad] = the kseed-th largest group
 // maximum minus twice the score uncertainty
 hipError_t launch_flat_prepass(int precision, const ScanParams& p, float* d_tau0, const TauBand& band, hipStream_t stream);
