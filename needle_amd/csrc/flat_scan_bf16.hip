@@ -53,8 +53,14 @@ typedef const __attribute__((address_space(1))) void glb_void;
 constexpr int BF_ROWS = 64;                               // rows per stage: half a 128-row tile
 constexpr int BF_BK = 128;                                // dims per stage
 constexpr int BF_STAGE_BYTES = BF_ROWS * BF_BK * 2;       // 16 KB
-constexpr int BF_NBUF = 4;                                // ring slots
-constexpr int BF_PD = 3;                                  // stages in flight ahead of the one being multiplied
+#ifndef BF_RING_SLOTS
+#define BF_RING_SLOTS 4
+#endif
+#ifndef BF_RING_AHEAD
+#define BF_RING_AHEAD 3
+#endif
+constexpr int BF_NBUF = BF_RING_SLOTS;                    // ring slots
+constexpr int BF_PD = BF_RING_AHEAD;                      // stages in flight ahead of the one being multiplied (< BF_NBUF)
 constexpr int BF_CSLOT = 1024;                            // per slot: the half tile's accumulator seeds, once per wave
 constexpr int BF_LDS_BYTES = BF_NBUF * (BF_STAGE_BYTES + BF_CSLOT);
 
@@ -104,6 +110,14 @@ __device__ inline void push_lane(const f32x16& acc, uint32_t row_base, uint32_t 
 template <int STAGES, bool CINIT>
 constexpr int bf_stage_loads(int u) { return 4 + ((CINIT && (u % STAGES) == 0) ? 1 : 0); }
 // loads issued behind stage u that may still be in flight when stage u is awaited
+// loads that may stay in flight while stage u + 1 is awaited at the fill point of stage u: those of stages
+// u + 2 .. u + BF_PD - 1 (stage u + BF_PD is issued right behind that wait)
+template <int STAGES, bool CINIT>
+constexpr int bf_steady_inflight(int u) {
+    int n = 0;
+    for (int j = 2; j < BF_PD; ++j) n += bf_stage_loads<STAGES, CINIT>(u + j);
+    return n;
+}
 template <int STAGES, bool CINIT>
 constexpr int bf_inflight_behind(int u) {
     int n = 0;
@@ -301,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
                             // The NEXT stage: this wave's pieces have landed (the stage after it may be in flight);
                             // behind the barrier everybody's have, and everybody has left the previous stage, whose
                             // slot takes the stage three ahead, one piece per k-step from here on.
-                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_stage_loads<STAGES, CINIT>(u + 2)) : "memory");
+                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_steady_inflight<STAGES, CINIT>(u)) : "memory");
                             __builtin_amdgcn_s_barrier();
                         }
                         if (BF_FILL_SPREAD) {
