@@ -245,6 +245,16 @@ needle_hip_status needle_hip_pq_train(needle_hip_ctx* ctx, const float* vectors,
 needle_hip_status needle_hip_pq_encode(needle_hip_ctx* ctx, const float* codebooks, uint32_t dim, uint32_t m,
                                        const uint32_t* ncent, const float* vectors, uint64_t n, uint8_t* out_codes);
 
+/* IVF-PQ (IvfConfig::use_pq, src/indexing/ivf.rs:488-491, 536-546): as
+ * needle_hip_ivf_build, but a list keeps ProductQuantizer::encode(vector) and a
+ * search scores the probed lists with ProductQuantizer::asymmetric_distance
+ * (src/indexing/quantization.rs:449-465).  codebooks: [m][256][dim/m] host f32.
+ * The rows are encoded on the device and not kept. */
+needle_hip_status needle_hip_ivf_pq_build(needle_hip_ctx* ctx, const float* base, uint64_t n, uint32_t dim,
+                                          const float* centroids, uint32_t nlist, const uint32_t* assignment,
+                                          const uint32_t* valid_bitmask, uint32_t m, const float* codebooks,
+                                          needle_hip_index** out);
+
 /* ---- quantized (ADC) indexes ------------------------------------------- */
 
 /* A code matrix scored with ProductQuantizer::{compute_distance_table,

@@ -400,6 +400,9 @@ needle_hip_status nh::run_exact(needle_hip_index* ix, const float* d_queries, co
         p.prefix = ix->x_u64.as<uint64_t>();
         p.sel = ix->x_sel.as<uint64_t>();
         p.f = f; p.n = n; p.dim = ix->dim; p.k = k; p.metric = ix->metric; p.arith = ix->arith;
+        if (ix->kind == KIND_IVF && ix->pq_m) {
+            p.pq_codes = ix->d_codes; p.pq_books = ix->d_codebooks; p.pq_m = ix->pq_m; p.pq_dsub = ix->pq_dsub;
+        }
         if (ix->kind == KIND_SQ8) {
             p.sq_codes = ix->d_codes; p.sq_min = ix->d_sq_min; p.sq_scale = ix->d_sq_scale; p.sq_stride = ix->dpad_f32;
         }
@@ -440,7 +443,7 @@ needle_hip_status nh::ensure_bf16_copy(needle_hip_index* ix) {
     hipError_t e = hipMalloc((void**)&d_bits, 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(d_bits, 0, 2 * sizeof(uint32_t), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d, 0, bytes, c->stream);
-    const bool sq8 = ix->kind == KIND_SQ8, pq = ix->kind == KIND_PQ;
+    const bool sq8 = ix->kind == KIND_SQ8, pq = ix->pq_m != 0;  // PQ index, or IVF lists holding PQ codes
     if (e == hipSuccess && pq) {
         // the decoded rows are the operand: score = q.row - |row|^2/2, as a Euclidean flat index over them
         if (!ix->d_cinit) {
@@ -448,7 +451,7 @@ needle_hip_status nh::ensure_bf16_copy(needle_hip_index* ix) {
             if (e == hipSuccess) e = hipMemsetAsync(ix->d_cinit, 0, (size_t)ix->n_pad * sizeof(float), c->stream);
         }
         if (e == hipSuccess)
-            e = launch_pq_decode_bf16(ix->d_codes, ix->d_codebooks, ix->n, ix->pq_m, ix->pq_dsub, ix->dpad_bf16, d, ix->d_cinit,
+            e = launch_pq_decode_bf16(ix->d_codes, ix->d_codebooks, ix->kind == KIND_IVF ? ix->n_pad : ix->n, ix->pq_m, ix->pq_dsub, ix->dpad_bf16, d, ix->d_cinit,
                                       d_bits, c->stream);
         uint32_t two[2] = {0, 0};
         if (e == hipSuccess) e = hipMemcpyAsync(two, d_bits, sizeof(two), hipMemcpyDeviceToHost, c->stream);

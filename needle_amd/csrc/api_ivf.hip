@@ -250,9 +250,31 @@ __global__ __launch_bounds__(256) void ivf_regroup_items_kernel(RegroupBufs g) {
             g.items[at++] = nh::IvfItem{t0 + ch * g.run, t0 + min(nt, (ch + 1) * g.run), g.pair_off[e] + o, min(g.item_queries, c - o), ch};
 }
 
+static needle_hip_status ivf_build_impl(needle_hip_ctx* c, const float* base, uint64_t n, uint32_t dim, const float* centroids,
+                                        uint32_t nlist, const uint32_t* assignment, const uint32_t* valid_bitmask, uint32_t pq_m,
+                                        const float* pq_codebooks, needle_hip_index** out);
+
 extern "C" needle_hip_status needle_hip_ivf_build(needle_hip_ctx* c, const float* base, uint64_t n, uint32_t dim,
                                                   const float* centroids, uint32_t nlist, const uint32_t* assignment,
                                                   const uint32_t* valid_bitmask, needle_hip_index** out) {
+    return ivf_build_impl(c, base, n, dim, centroids, nlist, assignment, valid_bitmask, 0, nullptr, out);
+}
+
+extern "C" needle_hip_status needle_hip_ivf_pq_build(needle_hip_ctx* c, const float* base, uint64_t n, uint32_t dim,
+                                                     const float* centroids, uint32_t nlist, const uint32_t* assignment,
+                                                     const uint32_t* valid_bitmask, uint32_t m, const float* codebooks,
+                                                     needle_hip_index** out) {
+    if (m == 0 || !codebooks || dim % m != 0)
+        return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "need codebooks and dim (%u) divisible by the subvector count (%u)", dim, m);
+    if (dim / m > 64) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "sub-vectors of %u dimensions do not fit the on-chip codebook", dim / m);
+    if (flat_scan_bf16_dpad(dim) == 0)
+        return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "IVF-PQ lists are scored through a bf16 copy of the decoded rows: at most 768 dimensions");
+    return ivf_build_impl(c, base, n, dim, centroids, nlist, assignment, valid_bitmask, m, codebooks, out);
+}
+
+static needle_hip_status ivf_build_impl(needle_hip_ctx* c, const float* base, uint64_t n, uint32_t dim, const float* centroids,
+                                        uint32_t nlist, const uint32_t* assignment, const uint32_t* valid_bitmask, uint32_t pq_m,
+                                        const float* pq_codebooks, needle_hip_index** out) {
     if (!c || !out) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (dim == 0) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "dimension must be positive");
@@ -342,7 +364,24 @@ extern "C" needle_hip_status needle_hip_ivf_build(needle_hip_ctx* c, const float
     }
     if (d_src) (void)hipFree(d_src);
     if (e != hipSuccess) st = hip_fail(e, "building the IVF layout");
-    if (st == NEEDLE_HIP_OK) st = finish_operands(ix, false);
+    if (st == NEEDLE_HIP_OK && pq_m) {
+        // IVF-PQ (ivf.rs:488-491): a list keeps pq.encode(vector), not the vector.  Encode the list-ordered rows,
+        // drop them, and build the operand of the list scan from the decoded codes.
+        ix->pq_m = pq_m;
+        ix->pq_dsub = dim / pq_m;
+        const size_t cb_bytes = (size_t)pq_m * 256 * ix->pq_dsub * sizeof(float);
+        e = hipMalloc((void**)&ix->d_codebooks, cb_bytes);
+        if (e == hipSuccess) e = hipMemcpyAsync(ix->d_codebooks, pq_codebooks, cb_bytes, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && ix->n_pad > 0) {
+            e = hipMalloc((void**)&ix->d_codes, (size_t)ix->n_pad * pq_m + 16);
+            if (e == hipSuccess) e = launch_pq_encode(ix->d_raw, ix->n_pad, dim, pq_m, ix->d_codebooks, nullptr, ix->d_codes, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            (void)hipFree(ix->d_raw);
+            ix->d_raw = nullptr;
+        }
+        if (e != hipSuccess) st = hip_fail(e, "encoding the lists");
+        if (st == NEEDLE_HIP_OK && ix->n_pad > 0) st = ensure_bf16_copy(ix);  // decoded rows, -|row|^2/2, max norm, rounding error
+    } else if (st == NEEDLE_HIP_OK) st = finish_operands(ix, false);
     if (st == NEEDLE_HIP_OK && ix->n_pad > 0 && ix->d_cinit) {
         hipLaunchKernelGGL(ivf_pad_seed_kernel, dim3((ix->n_pad + 255) / 256), dim3(256), 0, c->stream, ix->d_pos2id, ix->n_pad,
                            ix->d_cinit);
@@ -430,12 +469,13 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     const uint32_t* d_probe_n = ix->v_probe_n.as<uint32_t>();
 
     // bf16 is a hint, as in the flat search: dimensions beyond the register-resident query block use fp32
-    bool bf16 = precision == NEEDLE_PRECISION_BF16 && flat_scan_bf16_dpad(ix->dim) != 0;
+    const bool pq = ix->pq_m != 0;  // lists of PQ codes: only the bf16 copy of the decoded rows exists, so bf16 it is
+    bool bf16 = (precision == NEEDLE_PRECISION_BF16 || pq) && flat_scan_bf16_dpad(ix->dim) != 0;
     if (bf16 && choose_kprime((uint32_t)std::min<uint64_t>(k, ix->n), NEEDLE_PRECISION_BF16) > KPRIME_MAX) bf16 = false;
     const int scan_precision = bf16 ? NEEDLE_PRECISION_BF16 : NEEDLE_PRECISION_FP32;
     const uint32_t lpe = bf16 ? 2 : 1;  // candidate lists per (query, list run): the bf16 kernel keeps one per lane half
     const uint32_t kprime = choose_kprime((uint32_t)std::min<uint64_t>(k, ix->n), scan_precision);
-    const bool exact_only = precision == NEEDLE_PRECISION_EXACT_SCAN || kprime > KPRIME_MAX;
+    const bool exact_only = precision == NEEDLE_PRECISION_EXACT_SCAN || kprime > KPRIME_MAX || (pq && !bf16);
     if (exact_only) {
         ST_TRY(run_exact(ix, d_queries, nullptr, q, k, d_filter, d_out_ids, d_out_dists, d_out_counts, d_probe, d_probe_n, np));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -604,6 +644,9 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     pp.max_norm = ix->max_norm;
     pp.qerr = bf16 ? ix->w_qerr.as<float>() : nullptr;
     pp.berr = ix->bf16_err;
+    if (pq) {  // candidates are re-scored with ProductQuantizer::asymmetric_distance on the codes (ivf.rs:540)
+        pp.pq_codes = ix->d_codes; pp.pq_books = ix->d_codebooks; pp.pq_m = ix->pq_m; pp.pq_dsub = ix->pq_dsub; pp.pq_asym = 1;
+    }
     HIP_TRY(ix->w_cscore.ensure((size_t)q * kprime * sizeof(float)));
     pp.cand_scores = ix->w_cscore.as<float>();
     HIP_TRY(launch_merge_select(pp, c->stream));

@@ -479,8 +479,10 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams
     if (j < KPRIME_MAX) spos[j] = pos;
     if (p.pq_codes) {
         if (j < nc)
-            d = canon_distance(exact_pq(p.query_raw + (uint64_t)q * p.dim, p.pq_codes + (uint64_t)pos * p.pq_m, p.pq_books, p.pq_m,
-                                        p.pq_dsub));
+            d = canon_distance(p.pq_asym ? exact_pq_asym(p.query_raw + (uint64_t)q * p.dim, p.pq_codes + (uint64_t)pos * p.pq_m,
+                                                         p.pq_books, p.pq_m, p.pq_dsub)
+                                         : exact_pq(p.query_raw + (uint64_t)q * p.dim, p.pq_codes + (uint64_t)pos * p.pq_m, p.pq_books,
+                                                    p.pq_m, p.pq_dsub));
     } else if (p.sq_codes) {
         if (j < nc)
             d = canon_distance(exact_sq8(p.query_raw + (uint64_t)q * p.dim, p.sq_codes + (uint64_t)pos * p.sq_stride,
@@ -642,12 +644,12 @@ __global__ __launch_bounds__(EX_ROWS) void exact_keys_kernel(ExactParams p) {
         live[s] = row_ok && (uint32_t)s < slots;
         if (live[s] && p.pos_filter) live[s] = bit_set(p.pos_filter + (uint64_t)f * p.pos_filter_words, i);
     }
-    const bool sq8 = p.sq_codes != nullptr;
-    const int kind = sq8 ? (int)RK_RS_L2 : ref_kind(p.metric, p.arith);
+    const bool sq8 = p.sq_codes != nullptr, pq = p.pq_codes != nullptr;
+    const int kind = (sq8 || pq) ? (int)RK_RS_L2 : ref_kind(p.metric, p.arith);
     RefAcc acc[EX_SLOTS];
-    // Rust's f32 Sum folds from -0.0; the accelerator's sums, the SQ8 sum, the Hamming count and the
+    // Rust's f32 Sum folds from -0.0; the accelerator's sums, the SQ8 and PQ asymmetric sums, the Hamming count and the
     // Chebyshev fold start from +0.0
-    const float zero = (sq8 || p.arith == NEEDLE_ARITH_ACCEL_CHUNK4 || kind == RK_HAMMING || kind == RK_CHEB) ? 0.0f : -0.0f;
+    const float zero = (sq8 || pq || p.arith == NEEDLE_ARITH_ACCEL_CHUNK4 || kind == RK_HAMMING || kind == RK_CHEB) ? 0.0f : -0.0f;
 #pragma unroll
     for (int s = 0; s < EX_SLOTS; ++s) { acc[s].a = zero; acc[s].b = zero; acc[s].c = zero; }
 
@@ -667,6 +669,9 @@ __global__ __launch_bounds__(EX_ROWS) void exact_keys_kernel(ExactParams p) {
                 if (sq8) {  // decoded exactly as ScalarQuantizer::dequantize / asymmetric_distance do
                     const float cv = (float)p.sq_codes[(uint64_t)(row0 + r) * p.sq_stride + c0 + j];
                     v = (cv / p.sq_scale[c0 + j]) + p.sq_min[c0 + j];
+                } else if (pq) {  // the centroid value asymmetric_distance subtracts at this dimension
+                    const uint32_t dd = c0 + j, sub = dd / p.pq_dsub;
+                    v = p.pq_books[((uint64_t)sub * 256 + p.pq_codes[(uint64_t)(row0 + r) * p.pq_m + sub]) * p.pq_dsub + dd % p.pq_dsub];
                 } else {
                     v = p.base_raw[(uint64_t)(row0 + r) * p.dim + c0 + j];
                 }

@@ -145,6 +145,19 @@ __device__ inline float exact_pq(const float* __restrict__ q, const uint8_t* __r
     return sqrtf(dist);
 }
 
+// ProductQuantizer::asymmetric_distance, src/indexing/quantization.rs:449-465 (the distance of an IVF-PQ list scan,
+// src/indexing/ivf.rs:538-546): ONE accumulator from +0.0 across all subspaces and dimensions, then sqrt.
+__device__ inline float exact_pq_asym(const float* __restrict__ q, const uint8_t* __restrict__ codes,
+                                      const float* __restrict__ codebooks, uint32_t m, uint32_t dsub) {
+    float dist = 0.0f;
+    for (uint32_t s = 0; s < m; ++s) {
+        const float* c = codebooks + ((uint64_t)s * 256 + codes[s]) * dsub;
+        const float* x = q + s * dsub;
+        for (uint32_t j = 0; j < dsub; ++j) { const float d = x[j] - c[j]; const float sq = d * d; dist = dist + sq; }
+    }
+    return sqrtf(dist);
+}
+
 __device__ inline float exact_distance(int metric, int arith, const float* __restrict__ q,
                                        const float* __restrict__ b, uint32_t dim) {
     return arith == NEEDLE_ARITH_ACCEL_CHUNK4 ? exact_chunk4(metric, q, b, dim)

@@ -81,6 +81,9 @@ hipError_t launch_sq8_query_prep(const float* d_queries, uint32_t q, uint32_t di
                                  const float* d_scale, float* d_qop, uint16_t* d_qop_bf16, double* d_qconst,
                                  double* d_qscaled_err2, hipStream_t stream);
 // bf16 operand copy [n][dpad] of a u8 code matrix [n][stride] (exact); d_out is zero-filled by the caller.
+// ProductQuantizer::encode of device-resident rows (train.hip): out [n][m]
+hipError_t launch_pq_encode(const float* d_v, uint32_t n, uint32_t dim, uint32_t m, const float* d_books, const uint32_t* d_ncent,
+                            uint8_t* d_out, hipStream_t stream);
 // decoded PQ rows as the bf16 operand of the matrix-core scan, with -|row|^2/2, max |row| and max rounding error (prep.hip)
 hipError_t launch_pq_decode_bf16(const uint8_t* d_codes, const float* d_books, uint64_t n, uint32_t m, uint32_t dsub, uint32_t dpad,
                                  uint16_t* d_op_bf16, float* d_cinit, uint32_t* d_max_bits, hipStream_t stream);
@@ -113,6 +116,7 @@ struct PostParams {
     const uint8_t* pq_codes;  // PQ rows scored through their decoded bf16 copy: [n][pq_m] codes, else null
     const float* pq_books;    // [pq_m][256][pq_dsub]
     uint32_t pq_m, pq_dsub;
+    int pq_asym;              // 1: asymmetric_distance's single accumulator (IVF-PQ); 0: the distance-table sums
     const float* sq_min;      // [dim]
     const float* sq_scale;    // [dim]
     uint32_t sq_stride;
@@ -165,6 +169,9 @@ struct ExactParams {
     const uint32_t* filter;
     const uint32_t* pos2id;   // rows are positions of a list-ordered copy: their row ids (~0 padding), or null
     const uint32_t* pos_filter;  // [f][pos_filter_words] per-slot bitmask over positions, or null
+    const uint8_t* pq_codes;  // product-quantized rows [n][pq_m] scored by asymmetric_distance (IVF-PQ), or null
+    const float* pq_books;
+    uint32_t pq_m, pq_dsub;
     const uint8_t* sq_codes;  // scalar-quantized rows (see PostParams) or null
     const float* sq_min;
     const float* sq_scale;

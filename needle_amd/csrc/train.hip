@@ -292,20 +292,6 @@ __global__ __launch_bounds__(256) void pq_encode_kernel(const float* __restrict_
     out[(uint64_t)row * m + s] = (uint8_t)best;
 }
 
-hipError_t launch_pq_encode(const float* d_v, uint32_t n, uint32_t dim, uint32_t m, const float* d_books, const uint32_t* d_ncent,
-                            uint8_t* d_out, hipStream_t stream) {
-    const uint32_t dsub = dim / m;
-    const dim3 grid((n + 255) / 256, m), block(256);
-    const size_t lds = (size_t)256 * dsub * sizeof(float);
-    switch (dsub) {
-    case 4: hipLaunchKernelGGL(pq_encode_kernel<4>, grid, block, lds, stream, d_v, n, dim, dsub, d_books, d_ncent, m, d_out); break;
-    case 8: hipLaunchKernelGGL(pq_encode_kernel<8>, grid, block, lds, stream, d_v, n, dim, dsub, d_books, d_ncent, m, d_out); break;
-    case 16: hipLaunchKernelGGL(pq_encode_kernel<16>, grid, block, lds, stream, d_v, n, dim, dsub, d_books, d_ncent, m, d_out); break;
-    default: hipLaunchKernelGGL(pq_encode_kernel<0>, grid, block, lds, stream, d_v, n, dim, dsub, d_books, d_ncent, m, d_out); break;
-    }
-    return hipGetLastError();
-}
-
 // seeding: dist[i] = min(dist[i], |sub-vector i - centroid|^2)
 __global__ __launch_bounds__(256) void pq_seed_distance_kernel(const float* __restrict__ v, uint32_t n, uint32_t dim, uint32_t off,
                                                                uint32_t dsub, const float* __restrict__ centroid,
@@ -455,6 +441,20 @@ needle_hip_status pq_train_impl(needle_hip_ctx* c, const float* vectors, uint64_
 }
 
 }  // namespace
+
+hipError_t nh::launch_pq_encode(const float* d_v, uint32_t n, uint32_t dim, uint32_t m, const float* d_books, const uint32_t* d_ncent,
+                            uint8_t* d_out, hipStream_t stream) {
+    const uint32_t dsub = dim / m;
+    const dim3 grid((n + 255) / 256, m), block(256);
+    const size_t lds = (size_t)256 * dsub * sizeof(float);
+    switch (dsub) {
+    case 4: hipLaunchKernelGGL(pq_encode_kernel<4>, grid, block, lds, stream, d_v, n, dim, dsub, d_books, d_ncent, m, d_out); break;
+    case 8: hipLaunchKernelGGL(pq_encode_kernel<8>, grid, block, lds, stream, d_v, n, dim, dsub, d_books, d_ncent, m, d_out); break;
+    case 16: hipLaunchKernelGGL(pq_encode_kernel<16>, grid, block, lds, stream, d_v, n, dim, dsub, d_books, d_ncent, m, d_out); break;
+    default: hipLaunchKernelGGL(pq_encode_kernel<0>, grid, block, lds, stream, d_v, n, dim, dsub, d_books, d_ncent, m, d_out); break;
+    }
+    return hipGetLastError();
+}
 
 extern "C" needle_hip_status needle_hip_pq_train(needle_hip_ctx* c, const float* vectors, uint64_t n, uint32_t dim, uint32_t m,
                                                  uint32_t iterations, uint64_t seed, float* out_codebooks, uint32_t* out_ncent) {

@@ -42,6 +42,9 @@ class IvfConfig:  # src/indexing/ivf.rs:106-137
     def with_tolerance(self, tol: float) -> "IvfConfig":
         return dataclasses.replace(self, tolerance=tol)
 
+    def with_pq(self, subvectors: int) -> "IvfConfig":  # ivf.rs:164-168
+        return dataclasses.replace(self, use_pq=True, pq_subvectors=subvectors)
+
 
 class NotTrained(_lib.NeedleHipError):
     """IvfError::NotTrained."""
@@ -52,9 +55,8 @@ class IvfIndex:
                  ctx: Context | None = None, seed: int = 1):
         self.dimensions = dimensions
         self.config = config or IvfConfig()
-        if self.config.use_pq:
-            raise _lib.NeedleHipError(_lib.ERR_UNSUPPORTED, "IVF-PQ lists are not available on the device yet")
         self.ctx = ctx or Context(device)
+        self.pq = None  # ProductQuantizer of the lists when config.use_pq (ivf.rs:321-323)
         self.seed = seed
         self.centroids: np.ndarray | None = None
         self._ids: List[int] = []
@@ -97,6 +99,18 @@ class IvfIndex:
                                                    self.config.tolerance, self.seed, c.ctypes.data, C.byref(got)))
         c = np.ascontiguousarray(c[: got.value])
         self.centroids = c
+        if self.config.use_pq:  # ivf.rs:321-323: the list quantizer is trained on the same rows
+            from .quantization import ProductQuantizer
+
+            self.pq = ProductQuantizer.train_device(self.ctx, v, self.config.pq_subvectors, seed=self.seed)
+        self._dirty = True
+
+    def set_pq(self, pq) -> None:
+        """Use a given (already trained) ProductQuantizer for the lists."""
+        if pq.dimensions != self.dimensions:
+            raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                         f"Dimension mismatch: expected {self.dimensions}, got {pq.dimensions}")
+        self.pq = pq
         self._dirty = True
 
     # ---- insert: ivf.rs:462-506 ----------------------------------------------
@@ -142,9 +156,18 @@ class IvfIndex:
             self.close()
             base = np.stack(self._rows) if self._rows else np.zeros((0, self.dimensions), dtype=np.float32)
             self._h = C.c_void_p()
-            _lib.check(_lib.lib().needle_hip_ivf_build(self.ctx._h, base.ctypes.data if base.shape[0] else None,
-                                                       base.shape[0], self.dimensions, self.centroids.ctypes.data,
-                                                       self.centroids.shape[0], None, None, C.byref(self._h)))
+            if self.config.use_pq:
+                if self.pq is None:
+                    raise NotTrained(_lib.ERR_NOT_TRAINED, "Index not trained")
+                books = np.ascontiguousarray(self.pq.codebooks, dtype=np.float32)
+                _lib.check(_lib.lib().needle_hip_ivf_pq_build(self.ctx._h, base.ctypes.data if base.shape[0] else None,
+                                                              base.shape[0], self.dimensions, self.centroids.ctypes.data,
+                                                              self.centroids.shape[0], None, None, self.pq.num_subvectors,
+                                                              books.ctypes.data, C.byref(self._h)))
+            else:
+                _lib.check(_lib.lib().needle_hip_ivf_build(self.ctx._h, base.ctypes.data if base.shape[0] else None,
+                                                           base.shape[0], self.dimensions, self.centroids.ctypes.data,
+                                                           self.centroids.shape[0], None, None, C.byref(self._h)))
             self._dirty = False
         return self._h
 

@@ -227,3 +227,44 @@ def test_ivf_under_row_masks(ctx, oracle):
     ids, _, counts = ix.batch_search_arrays(queries, k, filter_mask=np.zeros(n, dtype=bool))
     assert counts.tolist() == [0] * 150
     ix.close()
+
+
+@pytest.mark.parametrize("shape", [(20000, 64, 32, 6, 8, 10), (8000, 96, 16, 16, 12, 5)])
+def test_ivf_pq_lists(ctx, oracle, shape):
+    """IvfConfig::use_pq: lists keep pq.encode(vector), the scan scores ProductQuantizer::asymmetric_distance
+    (ivf.rs:488-491, 536-546).  Codes equal the oracle's, hits bit-equal, for every precision setting."""
+    from needle_amd.ivf import IvfConfig, IvfIndex
+    from needle_amd.quantization import ProductQuantizer
+
+    n, d, nlist, nprobe, m, k = shape
+    rng = np.random.default_rng(n + m)
+    base = rng.standard_normal((n, d)).astype(F)
+    cents = oracle.ivf_kmeans(base[: 20 * nlist], nlist, max_iter=5, seed=2)
+    opq = oracle.ProductQuantizer.train(base[:2000], m, seed=4)
+    codes = opq.encode(base)
+    codes_dup = codes.copy()
+    ix = IvfIndex(d, IvfConfig.new(nlist).with_nprobe(nprobe).with_pq(m), ctx=ctx)
+    ix.set_centroids(cents)
+    ix.set_pq(ProductQuantizer(opq.codebooks))
+    ix.add(range(n), base)
+    assign = oracle.ivf_assign(base, cents)
+    offsets, order = oracle.ivf_lists_from_assignment(assign, nlist)
+    queries = np.concatenate([base[:4], rng.standard_normal((90, d)).astype(F)])
+    oi, od, oc = oracle.ivf_batch_search(queries, None, cents, offsets, order, nprobe, k, pq_codes=codes_dup,
+                                         pq_codebooks=opq.codebooks, pq_m=m)
+    for precision in ("fp32", "bf16", "exact"):
+        ids, dists, counts = ix.batch_search_arrays(queries, k, precision=precision)
+        assert np.array_equal(counts, oc), precision
+        for i in range(queries.shape[0]):
+            c = int(oc[i])
+            assert np.array_equal(ids[i, :c], oi[i, :c]), (precision, i, ids[i, :c], oi[i, :c])
+            assert np.array_equal(dists[i, :c].view(np.uint32), od[i, :c].view(np.uint32)), (precision, i)
+    # k beyond the candidate budget of the first pass: the exact scan over the codes
+    oi, od, oc = oracle.ivf_batch_search(queries[:6], None, cents, offsets, order, nprobe, 300, pq_codes=codes_dup,
+                                         pq_codebooks=opq.codebooks, pq_m=m)
+    ids, dists, counts = ix.batch_search_arrays(queries[:6], 300)
+    assert np.array_equal(counts, oc)
+    for i in range(6):
+        c = int(oc[i])
+        assert np.array_equal(ids[i, :c], oi[i, :c]) and np.array_equal(dists[i, :c].view(np.uint32), od[i, :c].view(np.uint32))
+    ix.close()
