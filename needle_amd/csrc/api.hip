@@ -726,9 +726,9 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     }
     // The rows a bf16 score cannot tell apart from the k-th hit must all be among the candidates kept.  How many
     // there are depends on the data (wide, unnormalised rows at large k: dozens), so the slack adapts: a batch that
-    // left more than 2 % of its queries undecided doubles it for the batches that follow.  Only the cost moves; the
+    // left more than 0.5 % of its queries undecided doubles it for the batches that follow.  Only the cost moves; the
     // hits are proven either way.
-    if (bf16 && q >= 32 && (uint64_t)n_flagged * 50 > q && kprime < (uint32_t)KPRIME_MAX)
+    if (bf16 && q >= 32 && (uint64_t)n_flagged * 200 > q && kprime < (uint32_t)KPRIME_MAX)
         ix->bf16_extra_slack = std::min<uint32_t>(ix->bf16_extra_slack ? ix->bf16_extra_slack * 2 : 48, KPRIME_MAX);
     if (n_flagged > 0) {
         if (n_flagged > q) n_flagged = q;
