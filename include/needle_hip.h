@@ -103,6 +103,7 @@ typedef struct needle_hip_metrics {
     double last_scan_ms;
     double last_search_ms;        /* device time of the last whole search (profiling on) */
     uint64_t refined_queries;     /* queries a bf16 first pass left undecided, re-run with the fp32 first pass */
+    uint64_t binary_code_scans;   /* full passes over a binary code matrix (2 or 3 per batch: see needle_hip_binary_build) */
 } needle_hip_metrics;
 
 /* ---- context --------------------------------------------------------- */

@@ -13,6 +13,8 @@
 //   C  scan: rows at T per (query, run of consecutive rows), then exclusive sums over the runs
 //   D  scan: collect rows below T, and rows at T whose rank among the ties (run prefix + position) < need
 //   E  emit: the k collected (distance, id) keys of a query, sorted
+// When no query has more than BIN_TIE_CAP rows at its T (the histogram says so after B: the usual case for k << n),
+// C is skipped: one scan collects the rows below T and ALL rows at T, and E keeps the `need` lowest ids of those.
 // Codes are stored word-major ([word][row], 64-bit words), so a wave reads 64 consecutive rows' words with one
 // coalesced load; a lane keeps QT distance counters and every loaded word is XORed with the QT query words of
 // the workgroup's query tile (LDS broadcast reads).  Integer work throughout.
@@ -34,9 +36,14 @@ struct BinParams {
     uint32_t* tiecnt;  // [q][units]; exclusive sums after pass C
     uint32_t* outn;    // [q]
     uint64_t* keys;    // [q][k]: distance << 32 | row
+    uint32_t* tien;    // [q] rows at T collected by the single-scan path
+    uint32_t* tierow;  // [q][BIN_TIE_CAP] their row ids, unordered
+    uint32_t* max_ties;  // [1] most rows at T of any query of the batch
 };
 
-enum { PASS_HIST = 0, PASS_TIES = 1, PASS_COLLECT = 2 };
+constexpr uint32_t BIN_TIE_CAP = 1024;
+
+enum { PASS_HIST = 0, PASS_TIES = 1, PASS_COLLECT = 2, PASS_COLLECT_ALL = 3 };
 
 template <int PASS, int QT>
 __global__ __launch_bounds__(256) void bin_scan_kernel(BinParams p) {
@@ -91,6 +98,16 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(BinParams p) {
                 for (int qi = 0; qi < QT; ++qi) {
                     const uint32_t T = thr_s[qi];
                     const bool tie = live && (uint32_t)qi < nq && d[qi] == T;
+                    if (PASS == PASS_COLLECT_ALL) {  // no ranking here: every row at T is kept for the emit step
+                        if (live && (uint32_t)qi < nq && d[qi] < T) {
+                            const uint32_t at = atomicAdd(&p.outn[q0 + qi], 1u);
+                            if (at < p.k) p.keys[(uint64_t)(q0 + qi) * p.k + at] = ((uint64_t)d[qi] << 32) | row;
+                        } else if (tie) {
+                            const uint32_t at = atomicAdd(&p.tien[q0 + qi], 1u);
+                            if (at < BIN_TIE_CAP) p.tierow[(uint64_t)(q0 + qi) * BIN_TIE_CAP + at] = row;
+                        }
+                        continue;
+                    }
                     const uint64_t tm = __builtin_amdgcn_ballot_w64(tie);
                     if (PASS == PASS_COLLECT) {
                         const bool take = live && (uint32_t)qi < nq && (d[qi] < T || (tie && ties[qi] + (uint32_t)__builtin_popcountll(tm & lt_mask) < need_s[qi]));
@@ -143,6 +160,7 @@ __global__ __launch_bounds__(256) void bin_pick_kernel(BinParams p, uint32_t* ou
     p.thr[q] = T;
     p.need[q] = need;
     out_counts[q] = min(total, p.k);
+    if (need) atomicMax(p.max_ties, h[T]);
 }
 
 // exclusive sums of a query's tie counts over the runs, in place; one workgroup per query
@@ -173,10 +191,25 @@ __global__ __launch_bounds__(256) void bin_tie_prefix_kernel(BinParams p) {
 constexpr uint32_t BIN_K_MAX = 1024;
 
 __global__ __launch_bounds__(256) void bin_emit_kernel(BinParams p, const uint32_t* counts, uint64_t* out_ids, float* out_dists,
-                                                       uint32_t out_ld) {  // out_ld >= p.k: length of an output row
+                                                       uint32_t out_ld, int ties_unranked) {  // out_ld >= p.k: length of an output row
     __shared__ uint64_t sk[BIN_K_MAX];
     const uint32_t q = blockIdx.x, t = threadIdx.x, c = min(counts[q], p.k);
-    for (uint32_t i = t; i < c; i += 256) sk[i] = p.keys[(uint64_t)q * p.k + i];
+    if (ties_unranked) {
+        // single-scan path: keys holds the rows below T; of the rows at T the `need` lowest ids complete the k
+        __shared__ uint32_t tr[BIN_TIE_CAP];
+        const uint32_t below = min(p.outn[q], p.k), tn = min(p.tien[q], BIN_TIE_CAP), need = p.need[q], T = p.thr[q];
+        for (uint32_t i = t; i < below; i += 256) sk[i] = p.keys[(uint64_t)q * p.k + i];
+        for (uint32_t i = t; i < tn; i += 256) tr[i] = p.tierow[(uint64_t)q * BIN_TIE_CAP + i];
+        __syncthreads();
+        for (uint32_t i = t; i < tn; i += 256) {
+            const uint32_t row = tr[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < tn; ++j) rank += tr[j] < row ? 1u : 0u;
+            if (rank < need && below + rank < p.k) sk[below + rank] = ((uint64_t)T << 32) | row;
+        }
+    } else {
+        for (uint32_t i = t; i < c; i += 256) sk[i] = p.keys[(uint64_t)q * p.k + i];
+    }
     __syncthreads();
     for (uint32_t i = t; i < c; i += 256) {
         const uint64_t key = sk[i];
@@ -323,7 +356,8 @@ needle_hip_status nh::binary_search_batch_device(needle_hip_index* ix, const flo
     p.filter = d_filter;
     p.n = n; p.ld = ix->n_pad; p.q = q; p.k = k_eff;
 
-    const size_t words = (size_t)q * p.W * 2 + (size_t)q * p.hb + 3 * (size_t)q + (size_t)q * p.units + (size_t)q * k_eff * 2 + 64;
+    const size_t words = (size_t)q * p.W * 2 + (size_t)q * p.hb + 5 * (size_t)q + (size_t)q * p.units + (size_t)q * k_eff * 2 +
+                         (size_t)q * BIN_TIE_CAP + 64;
     HIP_TRY(ix->b_work.ensure(words * sizeof(uint32_t)));
     uint64_t* w64 = ix->b_work.as<uint64_t>();
     uint64_t* qcodes = w64;                          // [q][W]
@@ -333,9 +367,12 @@ needle_hip_status nh::binary_search_batch_device(needle_hip_index* ix, const flo
     p.thr = p.hist + (size_t)q * p.hb;
     p.need = p.thr + q;
     p.outn = p.need + q;
-    p.tiecnt = p.outn + q;                           // [q][units]
+    p.tien = p.outn + q;
+    p.max_ties = p.tien + q;                         // one word, zeroed with the counters (a whole [q] row is reserved)
+    p.tiecnt = p.max_ties + q;                       // [q][units]
+    p.tierow = p.tiecnt + (size_t)q * p.units;       // [q][BIN_TIE_CAP]
     p.qcodes = qcodes;
-    HIP_TRY(hipMemsetAsync(p.hist, 0, ((size_t)q * p.hb + 3 * (size_t)q) * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(p.hist, 0, ((size_t)q * p.hb + 5 * (size_t)q) * sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(bin_quantize_kernel, dim3(q, p.W), dim3(64), 0, c->stream, d_queries, ix->d_sq_min, ix->dim, p.W, qcodes,
                        (uint64_t)p.W, 1ull);
     HIP_TRY(hipGetLastError());
@@ -343,12 +380,21 @@ needle_hip_status nh::binary_search_batch_device(needle_hip_index* ix, const flo
     HIP_TRY(launch_scan<PASS_HIST>(p, qt, c->stream));
     hipLaunchKernelGGL(bin_pick_kernel, dim3(q), dim3(256), 0, c->stream, p, d_out_counts);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(launch_scan<PASS_TIES>(p, qt, c->stream));
-    hipLaunchKernelGGL(bin_tie_prefix_kernel, dim3(q), dim3(256), 0, c->stream, p);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(launch_scan<PASS_COLLECT>(p, qt, c->stream));
+    // few rows at the threshold distance for every query: one scan collects them all and the emit step ranks them
+    uint32_t max_ties = 0;
+    HIP_TRY(hipMemcpyAsync(&max_ties, p.max_ties, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const bool single_scan = max_ties <= BIN_TIE_CAP && !getenv("NEEDLE_HIP_DEBUG_BINARY_TWO_SCANS");
+    if (single_scan) {
+        HIP_TRY(launch_scan<PASS_COLLECT_ALL>(p, qt, c->stream));
+    } else {
+        HIP_TRY(launch_scan<PASS_TIES>(p, qt, c->stream));
+        hipLaunchKernelGGL(bin_tie_prefix_kernel, dim3(q), dim3(256), 0, c->stream, p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch_scan<PASS_COLLECT>(p, qt, c->stream));
+    }
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-    hipLaunchKernelGGL(bin_emit_kernel, dim3(q), dim3(256), 0, c->stream, p, d_out_counts, d_out_ids, d_out_dists, k_out);
+    hipLaunchKernelGGL(bin_emit_kernel, dim3(q), dim3(256), 0, c->stream, p, d_out_counts, d_out_ids, d_out_dists, k_out, single_scan ? 1 : 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->profiling) {
@@ -358,6 +404,10 @@ needle_hip_status nh::binary_search_batch_device(needle_hip_index* ix, const flo
         c->m.scan_launches += 1;
         c->m.scan_ms_total += ms;
         c->m.last_scan_ms = ms;
+    }
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        c->m.binary_code_scans += single_scan ? 2 : 3;
     }
     return NEEDLE_HIP_OK;
 }

@@ -1,5 +1,7 @@
 """Parity of the quantized (ADC) scans against the oracle's restatement of
 src/indexing/quantization.rs, through the C ABI: ids bit-exact, distances bit-equal."""
+import os
+
 import numpy as np
 import pytest
 
@@ -147,7 +149,13 @@ def test_binary_hamming_scan(ctx, oracle, shape):
     assert np.array_equal(bq.quantize_device(ctx, base[:300]), codes[:300])  # device encoder
     queries = rng.standard_normal((37, dim)).astype(F)
     ix = BinaryIndex(ctx, bq, codes)
-    _cmp(ix.search(queries, k), obq.batch_search(queries, codes, k))
+    want = obq.batch_search(queries, codes, k)
+    _cmp(ix.search(queries, k), want)  # few rows at the threshold distance: one collecting scan
+    os.environ["NEEDLE_HIP_DEBUG_BINARY_TWO_SCANS"] = "1"  # the ranked two-scan path on the same data
+    try:
+        _cmp(ix.search(queries, k), want)
+    finally:
+        del os.environ["NEEDLE_HIP_DEBUG_BINARY_TWO_SCANS"]
     ix.close()
 
 
