@@ -20,6 +20,33 @@ def test_header_and_binding_agree():
     assert sorted(_lib.EXPORTS) == _header_symbols()
 
 
+def _struct_fields(text, opener, c_style):
+    """(name, kind) of every field of a struct body; kind is 'u64' or 'f64'."""
+    body = text[text.index(opener):]
+    body = body[body.index("{") + 1: body.index("}")]
+    body = re.sub(r"/\*.*?\*/|//[^\n]*", "", body, flags=re.S)
+    if c_style:
+        pairs = re.findall(r"\b(uint64_t|double)\s+([a-z_0-9]+)\s*;", body)
+        return [(n, "u64" if t == "uint64_t" else "f64") for t, n in pairs]
+    return [(n, t) for n, t in re.findall(r"pub\s+([a-z_0-9]+)\s*:\s*(u64|f64)", body)]
+
+
+def test_metrics_struct_mirrors_agree():
+    """needle_hip_get_metrics writes the whole struct: a mirror that is shorter, or ordered differently, reads
+    garbage or is overrun.  The ctypes binding and the Rust block a maintainer copies must match the header."""
+    import ctypes as C
+
+    from needle_amd import _lib
+
+    header = _struct_fields(open(os.path.join(ROOT, "include", "needle_hip.h")).read(), "typedef struct needle_hip_metrics", True)
+    assert len(header) >= 9
+    binding = [(n, "u64" if t is C.c_uint64 else "f64" if t is C.c_double else str(t)) for n, t in _lib.Metrics._fields_]
+    assert binding == header
+    assert C.sizeof(_lib.Metrics) == 8 * len(header)
+    rust = _struct_fields(open(os.path.join(ROOT, "INTEGRATION.md")).read(), "pub struct needle_hip_metrics", False)
+    assert rust == header
+
+
 def test_library_exports_every_declared_symbol():
     from needle_amd import _lib
 
