@@ -47,6 +47,23 @@ def test_metrics_struct_mirrors_agree():
     assert rust == header
 
 
+def test_search_params_mirrors_agree():
+    """Same for needle_search_params, which every search call reads: field names and order."""
+    from needle_amd import _lib
+
+    def names(text, opener, pattern):
+        body = text[text.index(opener):]
+        body = re.sub(r"/\*.*?\*/|//[^\n]*", "", body[body.index("{") + 1: body.index("}")], flags=re.S)
+        return re.findall(pattern, body)
+
+    header = names(open(os.path.join(ROOT, "include", "needle_hip.h")).read(), "typedef struct needle_search_params",
+                   r"([a-z_0-9]+)\s*;")
+    assert header == ["k", "nprobe", "precision", "reserved", "filter_bitmask"]
+    assert [n for n, _ in _lib.SearchParams._fields_] == header
+    rust = names(open(os.path.join(ROOT, "INTEGRATION.md")).read(), "pub struct needle_search_params", r"pub\s+([a-z_0-9]+)\s*:")
+    assert rust == header
+
+
 def test_library_exports_every_declared_symbol():
     from needle_amd import _lib
 
