@@ -1,0 +1,92 @@
+"""Seeded random sweep of the flat search through the C ABI: metric, dimension, row count, k, first-pass precision
+and row masks drawn together, so that the pieces that share the path (threshold seeding, staged launches, masks folded
+into the accumulator seeds, candidate pruning, adaptive candidate slack, the refinement chain) meet in combinations
+the targeted tests do not spell out.  Same bar as everywhere: ids bit-exact, distances bit-equal to the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+F = np.float32
+U64MAX = np.iinfo(np.uint64).max
+METRICS = ["Cosine", "CosineNormalized", "Euclidean", "DotProduct", "Manhattan", "Chebyshev", "Hamming"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import needle_amd as na
+
+    c = na.Context(0)
+    yield c
+    c.close()
+
+
+def _case(rng):
+    # four in five cases on the matrix-core metrics, where seeding, staging, mask folding and pruning live
+    metric = str(rng.choice(METRICS[:4])) if rng.random() < 0.8 else str(rng.choice(METRICS[4:]))
+    dim = int(rng.choice([3, 17, 32, 64, 100, 128, 200, 384, 500, 768, 900]))
+    n = int(rng.choice([7, 130, 5000, 20000, 70000, 200000]))
+    nq = int(rng.choice([1, 2, 33, 130, 300]))
+    if metric in ("Manhattan", "Chebyshev", "Hamming"):  # exact scan only: keep the oracle and the scan short
+        n, dim = min(n, 5000), min(dim, 200)
+    while float(n) * dim * nq > 6e9:  # bounds the oracle's scalar work per call
+        nq = max(1, nq // 2) if nq > 33 else nq
+        dim = dim if nq > 33 else max(32, dim // 2)
+    k = int(rng.choice([1, 5, 10, 64, 100, 250, 400]))
+    precision = str(rng.choice(["fp32", "bf16", "bf16", "exact"])) if n <= 20000 else str(rng.choice(["fp32", "bf16", "bf16"]))
+    kind = str(rng.choice(["gauss", "uniform", "clustered", "scaled"]))
+    # few slices make them long: pre-pass thresholds and staged launches (a development switch of the library)
+    splits = int(rng.choice([0, 0, 4, 8])) if n >= 70000 else 0
+    return metric, dim, n, nq, k, precision, kind, splits
+
+
+def _rows(rng, n, dim, kind):
+    if kind == "uniform":
+        return rng.random((n, dim), dtype=F)
+    x = rng.standard_normal((n, dim)).astype(F)
+    if kind == "clustered":  # a few tight blobs, rows in blob order: close scores, clustered arrival
+        centres = rng.standard_normal((5, dim)).astype(F) * F(3.0)
+        x = (centres[np.sort(rng.integers(0, 5, n))] + x * F(0.05)).astype(F)
+    if kind == "scaled":     # magnitudes far from 1
+        x = (x * F(rng.choice([1e-3, 40.0]))).astype(F)
+    return x
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_random_flat_case(ctx, oracle, seed):
+    import needle_amd as na
+
+    rng = np.random.default_rng(1000 + seed)
+    metric, dim, n, nq, k, precision, kind, splits = _case(rng)
+    base, queries = _rows(rng, n, dim, kind), _rows(rng, nq, dim, kind)
+    if metric == "CosineNormalized":
+        base, queries = oracle.normalize_rows(base), oracle.normalize_rows(queries)
+    if rng.random() < 0.3 and n > 20:  # exact duplicates: ties decided by row id
+        base[n // 2: n // 2 + 9] = base[3]
+        queries[0] = base[3]
+    valid = (rng.random(n) > 0.3) if rng.random() < 0.5 else None
+    filt = (rng.random(n) < rng.choice([0.02, 0.5, 0.9])) if rng.random() < 0.5 else None
+    m = na.DistanceFunction[metric]
+    ix = na.FlatIndex(ctx, base, m, valid=valid)
+    tag = (metric, dim, n, nq, k, precision, kind, splits, valid is not None, filt is not None)
+    if splits:
+        os.environ["NEEDLE_HIP_DEBUG_SPLITS"] = str(splits)
+    try:
+        _run_twice(oracle, ix, queries, base, k, m, precision, valid, filt, nq, tag)
+    finally:
+        os.environ.pop("NEEDLE_HIP_DEBUG_SPLITS", None)
+        ix.close()
+
+
+def _run_twice(oracle, ix, queries, base, k, m, precision, valid, filt, nq, tag):
+    oi, od, oc = oracle.flat_batch_search(queries, base, k, int(m), valid=valid, filt=filt)
+    for _ in range(2):  # twice: the second search runs with whatever the first one adapted
+        ids, dists, counts = ix.search(queries, k, precision=precision, filter_mask=filt)
+        assert np.array_equal(counts, oc), tag
+        for i in range(nq):
+            c = int(oc[i])
+            assert np.array_equal(ids[i, :c], oi[i, :c]), (tag, i, ids[i, :c][:6], oi[i, :c][:6])
+            assert np.array_equal(dists[i, :c].view(np.uint32), od[i, :c].view(np.uint32)), (tag, i)
+            assert np.all(ids[i, c:] == U64MAX), (tag, i)
