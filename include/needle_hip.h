@@ -215,6 +215,28 @@ needle_hip_status needle_hip_ivf_list_sizes(const needle_hip_index* index, uint3
  * ivf.rs:509-567, with params->nprobe: the k nearest rows of the probed lists
  * by (distance, id). */
 
+/* ---- two-phase search ----------------------------------------------------- */
+
+/* A Euclidean flat index over the first `dims` dimensions of every row of a flat
+ * index (MatryoshkaTruncation::truncate, src/indexing/quantization.rs:801-804),
+ * built on the device from the resident rows; it inherits the live-row mask the
+ * full index has at this moment. */
+needle_hip_status needle_hip_flat_build_prefix(needle_hip_index* full, uint32_t dims, needle_hip_index** out);
+
+/* adaptive_search, src/indexing/quantization.rs:890-943, for q host queries of
+ * the full dimension: phase 1 takes the min(k * max(overfetch, 1), n) rows
+ * nearest over `coarse`'s prefix (Euclidean; by (distance, row)), phase 2 ranks
+ * them by the Euclidean distance over all dimensions and returns the k best with
+ * both distances.  Ties in the full distance go to the candidate with the LARGER
+ * (coarse distance, row), as the reference's stable sort of its farthest-first
+ * candidate list does (:922-939).  Phase 1 keeps the nearest candidates; the
+ * reference's heap evicts its nearest entry once full (:913-918), untested there.
+ * k * overfetch <= 2048. */
+needle_hip_status needle_hip_adaptive_search(needle_hip_index* full, needle_hip_index* coarse, const float* queries,
+                                             uint32_t q, uint32_t query_dim, uint32_t k, uint32_t overfetch,
+                                             uint64_t* out_ids, float* out_dists, float* out_coarse_dists,
+                                             uint32_t* out_counts);
+
 /* ---- training ------------------------------------------------------------- */
 
 /* IvfIndex::train's k-means, src/indexing/ivf.rs:330-450: k-means++ seeding,

@@ -30,7 +30,7 @@ EXPORTS = (
     "needle_hip_index_dimensions", "needle_hip_batch_search", "needle_hip_batch_search_device",
     "needle_hip_batch_distance", "needle_hip_kmeans_assign", "needle_hip_merge_topk_device",
     "needle_hip_ivf_build", "needle_hip_ivf_probe", "needle_hip_ivf_list_sizes", "needle_hip_pq_build",
-    "needle_hip_sq8_build", "needle_hip_binary_build", "needle_hip_binary_quantize", "needle_hip_ivf_train", "needle_hip_ivf_pq_build", "needle_hip_pq_train", "needle_hip_pq_encode",
+    "needle_hip_sq8_build", "needle_hip_binary_build", "needle_hip_binary_quantize", "needle_hip_ivf_train", "needle_hip_ivf_pq_build", "needle_hip_flat_build_prefix", "needle_hip_adaptive_search", "needle_hip_pq_train", "needle_hip_pq_encode",
 )
 
 
@@ -145,6 +145,10 @@ def lib() -> C.CDLL:
     L.needle_hip_sq8_build.argtypes = [vp, vp, u64, u32, vp, vp, vp, C.POINTER(vp)]
     L.needle_hip_ivf_train.restype = i32
     L.needle_hip_ivf_train.argtypes = [vp, vp, u64, u32, u32, u32, C.c_float, u64, vp, C.POINTER(u32)]
+    L.needle_hip_flat_build_prefix.restype = i32
+    L.needle_hip_flat_build_prefix.argtypes = [vp, u32, C.POINTER(vp)]
+    L.needle_hip_adaptive_search.restype = i32
+    L.needle_hip_adaptive_search.argtypes = [vp, vp, vp, u32, u32, u32, u32, vp, vp, vp, vp]
     L.needle_hip_ivf_pq_build.restype = i32
     L.needle_hip_ivf_pq_build.argtypes = [vp, vp, u64, u32, vp, u32, vp, vp, u32, vp, C.POINTER(vp)]
     L.needle_hip_pq_train.restype = i32

@@ -1067,6 +1067,60 @@ NDL_API float ndl_pq_distance_with_table(const float *table, const uint8_t *code
  *   kind 1: ProductQuantizer table scan: compute_distance_table once per
  *           query, distance_with_table per row, over u8[N][m]
  */
+/* ---- adaptive_search, src/indexing/quantization.rs:890-943 -------------------------------------------
+ * Phase 1: the coarse_k = k * max(overfetch, 1) rows nearest over the first `coarse_dims` dimensions
+ * (sqrt of euclidean_distance_squared of the truncated slices), by (distance, row) -- the intended set;
+ * evict_nearest != 0 reproduces the reference's heap, which once full replaces its NEAREST entry
+ * (:913-918), for forensics.  Phase 2: full-dimension distances; the candidates arrive farthest-first
+ * (into_sorted_vec of Reverse<..>, :922-926) and are STABLY sorted by full distance (:939), truncated to k.
+ * Returns the number of results. */
+typedef struct { float coarse; float full; uint64_t id; } ndl_ad_hit;
+static int ad_coarse_desc(const void *a, const void *b) {  /* (coarse, id) descending */
+    const ndl_ad_hit *x = (const ndl_ad_hit *)a, *y = (const ndl_ad_hit *)b;
+    int c = of_cmp(y->coarse, x->coarse);
+    if (c) return c;
+    return (y->id > x->id) - (y->id < x->id);
+}
+NDL_API size_t ndl_adaptive_search(const float *query, const float *vectors, uint64_t n, size_t dim,
+                                   size_t coarse_dims, size_t k, size_t overfetch, int evict_nearest,
+                                   uint64_t *out_ids, float *out_full, float *out_coarse) {
+    size_t coarse_k = k * (overfetch ? overfetch : 1);
+    if (k == 0 || n == 0) return 0;
+    if (coarse_dims > dim) coarse_dims = dim;
+    ndl_ad_hit *h = (ndl_ad_hit *)malloc(sizeof(ndl_ad_hit) * (coarse_k + 1));
+    size_t cnt = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        ndl_ad_hit x; x.id = i; x.full = 0.0f;
+        x.coarse = sqrtf(ndl_euclidean_squared(query, vectors + i * dim, coarse_dims));
+        if (cnt < coarse_k) { h[cnt++] = x; continue; }
+        /* find the entry the reference compares with: its heap's top is the NEAREST (smallest (d, id)) */
+        size_t lo = 0, hi = 0;
+        for (size_t j = 1; j < cnt; ++j) {
+            if (ad_coarse_desc(&h[j], &h[lo]) > 0) lo = j;  /* smaller (coarse, id) */
+            if (ad_coarse_desc(&h[j], &h[hi]) < 0) hi = j;  /* larger */
+        }
+        if (evict_nearest) {
+            if (of_cmp(x.coarse, h[lo].coarse) < 0) h[lo] = x;
+        } else {
+            ndl_ad_hit far = h[hi];
+            if (of_cmp(x.coarse, far.coarse) < 0 || (of_cmp(x.coarse, far.coarse) == 0 && x.id < far.id)) h[hi] = x;
+        }
+    }
+    qsort(h, cnt, sizeof(ndl_ad_hit), ad_coarse_desc);  /* farthest first, as the reference's candidate list */
+    for (size_t j = 0; j < cnt; ++j) h[j].full = sqrtf(ndl_euclidean_squared(query, vectors + h[j].id * dim, dim));
+    /* stable sort by full distance: insertion sort keeps the arrival order of equal keys */
+    for (size_t j = 1; j < cnt; ++j) {
+        ndl_ad_hit x = h[j];
+        size_t p = j;
+        while (p > 0 && of_cmp(h[p - 1].full, x.full) > 0) { h[p] = h[p - 1]; --p; }
+        h[p] = x;
+    }
+    size_t m = cnt < k ? cnt : k;
+    for (size_t j = 0; j < m; ++j) { out_ids[j] = h[j].id; out_full[j] = h[j].full; out_coarse[j] = h[j].coarse; }
+    free(h);
+    return m;
+}
+
 /* ---- BinaryQuantizer, src/indexing/quantization.rs:536-594 ------------------------------- */
 /* train (:545-571): thresholds = per-dimension mean, summed sequentially in f32, one divide by n as f32 */
 NDL_API void ndl_bq_train(const float *vectors, size_t n, size_t dim, float *thresholds) {

@@ -123,6 +123,8 @@ def _declare(L: C.CDLL) -> None:
     L.ndl_sq_batch_search.restype = None
     L.ndl_sq_batch_search.argtypes = [_f32p, sz, sz, _u8p, C.c_uint64, _f32p, _f32p, sz, _u32p, C.c_int, _u64p,
                                       _f32p, _u32p]
+    L.ndl_adaptive_search.restype = sz
+    L.ndl_adaptive_search.argtypes = [_f32p, _f32p, C.c_uint64, sz, sz, sz, sz, C.c_int, _u64p, _f32p, _f32p]
     L.ndl_bq_train.restype = None
     L.ndl_bq_train.argtypes = [_f32p, sz, sz, _f32p]
     L.ndl_bq_quantize.restype = None
@@ -581,3 +583,15 @@ class BinaryQuantizer:
         lib().ndl_bq_batch_search(_p(q, _f32p), nq, dim, _p(c, _u8p), n, _p(self.thresholds, _f32p), k, vp,
                                   threads or cpu_threads(), _p(ids, _u64p), _p(dists, _f32p), _p(counts, _u32p))
         return ids[:, :k], dists[:, :k], counts
+
+
+def adaptive_search(query, vectors, coarse_dims: int, k: int, overfetch: int, evict_nearest: bool = False):
+    """adaptive_search of src/indexing/quantization.rs:890-943 -> (ids, full distances, coarse distances)."""
+    q, v = _f32(query), _f32(vectors)
+    kk = max(k, 1)
+    ids = np.empty(kk, dtype=np.uint64)
+    full = np.empty(kk, dtype=np.float32)
+    coarse = np.empty(kk, dtype=np.float32)
+    m = lib().ndl_adaptive_search(_p(q, _f32p), _p(v, _f32p), v.shape[0], v.shape[1], coarse_dims, k, overfetch,
+                                  int(evict_nearest), _p(ids, _u64p), _p(full, _f32p), _p(coarse, _f32p))
+    return ids[:m], full[:m], coarse[:m]

@@ -244,3 +244,40 @@ def test_collection_filter_objects_and_ttl(ctx, oracle):
     check(col.batch_search_with_filter(queries, 10, Filter.eq("group", 3)), live & has_meta & (grp == 3), 10)
     assert col.expire_vectors() == int((~live).sum()) and len(col) == int(live.sum())
     check(col.batch_search(queries, 10), live, 10)
+
+
+@pytest.mark.parametrize("shape", [(4000, 64, (32, 16), 16, 10, 4), (20000, 384, (128, 64), 200, 10, 3),
+                                   (3000, 100, (50,), 50, 7, 1), (9, 8, (4, 2), 4, 20, 3), (6000, 256, (64,), 32, 100, 20)])
+def test_adaptive_search_two_phase(ctx, oracle, shape):
+    """adaptive_search (quantization.rs:890-943) on the device: prefix scan, full-dimension re-rank; ids, both
+    distances and the tie order equal the oracle's, per query."""
+    from needle_amd.matryoshka import AdaptiveIndex, MatryoshkaTruncation
+
+    n, dim, levels, coarse_dims, k, overfetch = shape
+    rng = np.random.default_rng(n + dim)
+    # leading dimensions carry most of the signal, as Matryoshka embeddings do
+    rows = (rng.standard_normal((n, dim)) * np.linspace(2.0, 0.2, dim)).astype(F)
+    if n > 100:
+        rows[50:56] = rows[7]            # identical rows: full-distance ties, decided by (coarse distance, row) descending
+        rows[60, : dim // 2] = rows[7, : dim // 2]
+    trunc = MatryoshkaTruncation(dim, levels)
+    queries = np.concatenate([rows[7:8], (rng.standard_normal((23, dim)) * np.linspace(2.0, 0.2, dim)).astype(F)])
+    ix = AdaptiveIndex(ctx, rows, trunc)
+    ids, full, coarse, counts = ix.search_arrays(queries, coarse_dims, k, overfetch)
+    eff = trunc.nearest_level(coarse_dims)
+    for i in range(queries.shape[0]):
+        oi, of, oc = oracle.adaptive_search(queries[i], rows, eff, k, overfetch)
+        c = len(oi)
+        assert counts[i] == c == min(k, min(k * max(overfetch, 1), n)), (i, counts[i], c)
+        assert np.array_equal(ids[i, :c], oi), (i, ids[i, :c], oi)
+        assert np.array_equal(_bits(full[i, :c]), _bits(of)) and np.array_equal(_bits(coarse[i, :c]), _bits(oc)), i
+        assert np.all(ids[i, c:] == U64MAX)
+    one = ix.adaptive_search(queries[0], coarse_dims, k, overfetch)
+    assert one[0].id in (7, 50, 51, 52, 53, 54, 55) if n > 100 else one[0].distance >= 0.0
+    assert one[0].distance == 0.0 if n > 100 else True
+    import needle_amd as na
+
+    with pytest.raises(na.DimensionMismatch):
+        ix.search_arrays(queries[:, : dim - 1], coarse_dims, k, overfetch)
+    assert ix.search_arrays(queries[:3], coarse_dims, 0, overfetch)[3].tolist() == [0, 0, 0]
+    ix.close()

@@ -395,3 +395,30 @@ def test_kat_binary_quantizer(oracle):
     assert np.array_equal(o.quantize(v), h.quantize(v)) and o.quantize(v).shape == (500, 5)
     ids, d, c = o.batch_search(v[:3], o.quantize(v), 4)
     assert ids[:, 0].tolist() == [0, 1, 2] and d[:, 0].tolist() == [0.0, 0.0, 0.0] and c.tolist() == [4, 4, 4]
+
+
+# ---- MatryoshkaTruncation / adaptive_search: src/indexing/quantization.rs:1296-1352 ------------------
+def test_kat_matryoshka_and_adaptive_search(oracle):
+    from needle_amd.matryoshka import MatryoshkaTruncation
+
+    trunc = MatryoshkaTruncation(384, [128, 64])
+    assert abs(trunc.correct_distance(1.0, 128) - 3.0) < 0.01                     # :1300-1306
+    assert abs(trunc.correct_distance(1.0, 384) - 1.0) < np.finfo(np.float32).eps
+    assert trunc.nearest_level(200) == 128 and trunc.nearest_level(64) == 64       # :1309-1314
+    assert trunc.nearest_level(32) == 384                                          # no level fits
+    assert abs(trunc.memory_savings(128) - 3.0) < 0.01 and abs(trunc.memory_savings(64) - 6.0) < 0.01  # :1317-1321
+    assert MatryoshkaTruncation(8, [2, 9, 0, 4]).truncation_levels == [4, 2]       # :768-769: descending, 0 < d < full
+    cal = MatryoshkaTruncation(8, [4, 2])                                          # :1324-1335
+    cal.calibrate(np.array([[(i * 8 + j) * 0.01 for j in range(8)] for i in range(50)], dtype=np.float32))
+    assert len(cal.variance_ratios) == 2 and cal.correct_distance(1.0, 4) > 0.0
+    assert cal.truncate(np.arange(8), 4).tolist() == [0, 1, 2, 3] and cal.truncate(np.arange(3), 9).size == 3  # :801-804
+    vectors = np.array([[1, 0, 0, 0, 0, 0, 0, 0], [0, 1, 0, 0, 0, 0, 0, 0], [0.9, 0.1, 0, 0, 0, 0, 0, 0]], dtype=np.float32)
+    ids, full, coarse = oracle.adaptive_search(vectors[0], vectors, MatryoshkaTruncation(8, [4, 2]).nearest_level(4), 2, 3)
+    assert len(ids) == 2 and ids[0] == 0                                           # :1338-1350
+    # the candidate list never fills here, so the reference's inverted eviction gives the same answer
+    ids2, _, _ = oracle.adaptive_search(vectors[0], vectors, 4, 2, 3, evict_nearest=True)
+    assert ids2.tolist() == ids.tolist()
+    # ties in the full distance: the candidate with the LARGER (coarse distance, row) comes first (:922-939)
+    tie = np.array([[0, 0, 1, 0], [0, 0, -1, 0], [0, 0, 1, 0], [3, 0, 0, 0]], dtype=np.float32)
+    ids3, full3, _ = oracle.adaptive_search(np.zeros(4, dtype=np.float32), tie, 2, 3, 2)
+    assert full3.tolist() == [1.0, 1.0, 1.0] and ids3.tolist() == [2, 1, 0]
