@@ -153,6 +153,16 @@ needle_hip_status needle_hip_flat_build_device(needle_hip_ctx* ctx, const float*
                                                needle_arith arith, const uint32_t* valid_bitmask_host,
                                                needle_hip_index** out);
 
+/* Same, from rows stored in half precision: F16Vector / Bf16Vector of
+ * src/indexing/float16.rs (:261-275, :335-358).  rows: n x dim host 16-bit patterns;
+ * they are widened on the device exactly as F16::to_f32 / Bf16::to_f32 do
+ * (:101-136, :223-225), and every distance is then the f32 arithmetic on the
+ * widened values, as the reference's half vectors compute theirs (:294-326). */
+typedef enum needle_half_kind { NEEDLE_HALF_F16 = 0, NEEDLE_HALF_BF16 = 1 } needle_half_kind;
+needle_hip_status needle_hip_flat_build_half(needle_hip_ctx* ctx, const uint16_t* rows, uint64_t n, uint32_t dim,
+                                             int half_kind, needle_metric metric, needle_arith arith,
+                                             const uint32_t* valid_bitmask, needle_hip_index** out);
+
 /* HnswIndex::delete / is_deleted bookkeeping seen by the scan
  * (search_methods.rs:205): replace the live-row mask (NULL = all live). */
 needle_hip_status needle_hip_index_set_valid_mask(needle_hip_index* index,

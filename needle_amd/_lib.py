@@ -25,7 +25,7 @@ ARITH_DISTANCE_RS, ARITH_ACCEL_CHUNK4 = range(2)
 EXPORTS = (
     "needle_hip_init", "needle_hip_shutdown", "needle_hip_last_error", "needle_hip_version",
     "needle_hip_set_profiling", "needle_hip_get_metrics", "needle_hip_reset_metrics", "needle_hip_metric_from_str",
-    "needle_hip_flat_build", "needle_hip_flat_build_rows", "needle_hip_flat_build_device",
+    "needle_hip_flat_build", "needle_hip_flat_build_rows", "needle_hip_flat_build_device", "needle_hip_flat_build_half",
     "needle_hip_index_set_valid_mask", "needle_hip_index_destroy", "needle_hip_index_len",
     "needle_hip_index_dimensions", "needle_hip_batch_search", "needle_hip_batch_search_device",
     "needle_hip_batch_distance", "needle_hip_kmeans_assign", "needle_hip_merge_topk_device",
@@ -145,6 +145,8 @@ def lib() -> C.CDLL:
     L.needle_hip_sq8_build.argtypes = [vp, vp, u64, u32, vp, vp, vp, C.POINTER(vp)]
     L.needle_hip_ivf_train.restype = i32
     L.needle_hip_ivf_train.argtypes = [vp, vp, u64, u32, u32, u32, C.c_float, u64, vp, C.POINTER(u32)]
+    L.needle_hip_flat_build_half.restype = i32
+    L.needle_hip_flat_build_half.argtypes = [vp, vp, u64, u32, i32, i32, i32, vp, C.POINTER(vp)]
     L.needle_hip_flat_build_prefix.restype = i32
     L.needle_hip_flat_build_prefix.argtypes = [vp, u32, C.POINTER(vp)]
     L.needle_hip_adaptive_search.restype = i32

@@ -287,6 +287,37 @@ extern "C" needle_hip_status needle_hip_flat_build(needle_hip_ctx* c, const floa
     return NEEDLE_HIP_OK;
 }
 
+extern "C" needle_hip_status needle_hip_flat_build_half(needle_hip_ctx* c, const uint16_t* rows, uint64_t n, uint32_t dim,
+                                                        int half_kind, needle_metric metric, needle_arith arith,
+                                                        const uint32_t* valid_bitmask, needle_hip_index** out) {
+    if (!c || !out) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (half_kind != NEEDLE_HALF_F16 && half_kind != NEEDLE_HALF_BF16)
+        return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "unknown half precision kind %d", half_kind);
+    if (n > 0 && !rows) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "rows is null");
+    HIP_TRY(hipSetDevice(c->device));
+    // upload the 16-bit rows (half the bytes of an f32 base), widen them on the device, then the usual build
+    uint16_t* d_half = nullptr;
+    float* d_rows = nullptr;
+    const uint64_t total = n * dim;
+    hipError_t e = hipSuccess;
+    if (total > 0) {
+        e = hipMalloc((void**)&d_half, total * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&d_rows, total * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpyAsync(d_half, rows, total * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = launch_half_widen(d_half, total, half_kind == NEEDLE_HALF_BF16, d_rows, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    needle_hip_status st = NEEDLE_HIP_OK;
+    if (e != hipSuccess)
+        st = fail(e == hipErrorOutOfMemory ? NEEDLE_HIP_ERR_OUT_OF_MEMORY : NEEDLE_HIP_ERR_HIP, "HIP error %d (%s) widening the rows", (int)e,
+                  hipGetErrorString(e));
+    if (st == NEEDLE_HIP_OK) st = needle_hip_flat_build_device(c, d_rows, n, dim, metric, arith, valid_bitmask, out);
+    if (d_half) (void)hipFree(d_half);
+    if (d_rows) (void)hipFree(d_rows);
+    return st;
+}
+
 extern "C" needle_hip_status needle_hip_flat_build_rows(needle_hip_ctx* c, const float* const* rows, uint64_t n,
                                                         uint32_t dim, needle_metric metric, needle_arith arith,
                                                         const uint32_t* valid_bitmask, needle_hip_index** out) {

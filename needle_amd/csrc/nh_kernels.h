@@ -213,6 +213,8 @@ hipError_t launch_scatter_results(const uint32_t* d_idx, uint32_t n, uint32_t k,
                                   const uint32_t* d_counts, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
                                   hipStream_t stream);
 
+// 16-bit rows (F16 or Bf16 of src/indexing/float16.rs) widened exactly to f32 (prep.hip)
+hipError_t launch_half_widen(const uint16_t* d_in, uint64_t total, bool bf16, float* d_out, hipStream_t stream);
 // per-search accumulator seeds with dead rows (deleted, filtered out, beyond n) at -inf (prep.hip)
 hipError_t launch_masked_seed(const float* d_seed, const uint32_t* d_valid, const uint32_t* d_filter, uint32_t n, uint32_t n_pad,
                               float* d_out, hipStream_t stream);

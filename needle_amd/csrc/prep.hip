@@ -217,6 +217,35 @@ hipError_t launch_pq_decode_bf16(const uint8_t* d_codes, const float* d_books, u
     return hipGetLastError();
 }
 
+// ---- half-precision rows -------------------------------------------------------------------------------------
+// F16::to_f32 / Bf16::to_f32, src/indexing/float16.rs:101-136, 223-225: exact widening; an f16 NaN becomes the
+// canonical quiet NaN (which the build then rejects like any NaN row).
+__device__ inline float half_to_f32(uint32_t bits, int bf16) {
+    if (bf16) return __uint_as_float(bits << 16);
+    const uint32_t sign = (bits >> 15) & 1u, exp = (bits >> 10) & 0x1fu, mant = bits & 0x3ffu;
+    if (exp == 0) {
+        if (mant == 0) return __uint_as_float(sign << 31);
+        const int sh = __builtin_clz(mant) - 21;  // shifts that bring the leading one to bit 10
+        const uint32_t m = (mant << sh) & 0x3ffu;
+        return __uint_as_float((sign << 31) | ((uint32_t)(127 - 15 + 1 - sh) << 23) | (m << 13));
+    }
+    if (exp == 31) return __uint_as_float((sign << 31) | (mant == 0 ? 0x7f800000u : 0x7fc00000u));
+    return __uint_as_float((sign << 31) | ((exp - 15 + 127) << 23) | (mant << 13));
+}
+
+__global__ void half_widen_kernel(const uint16_t* __restrict__ in, uint64_t total, int bf16, float* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) out[i] = half_to_f32(in[i], bf16);
+}
+
+hipError_t launch_half_widen(const uint16_t* d_in, uint64_t total, bool bf16, float* d_out, hipStream_t stream) {
+    if (total == 0) return hipSuccess;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 1u << 20);
+    hipLaunchKernelGGL(half_widen_kernel, dim3(grid), dim3(256), 0, stream, d_in, total, bf16 ? 1 : 0, d_out);
+    return hipGetLastError();
+}
+
 // Accumulator seeds of one search under row masks: a row that is deleted, filtered out or beyond n gets -inf, so
 // its first-pass score is -inf and it never passes a threshold -- the scan itself then runs without mask lookups.
 __global__ __launch_bounds__(256) void masked_seed_kernel(const float* __restrict__ seed, const uint32_t* __restrict__ valid,

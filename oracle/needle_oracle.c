@@ -1067,6 +1067,54 @@ NDL_API float ndl_pq_distance_with_table(const float *table, const uint8_t *code
  *   kind 1: ProductQuantizer table scan: compute_distance_table once per
  *           query, distance_with_table per row, over u8[N][m]
  */
+/* ---- half precision storage, src/indexing/float16.rs -------------------------------------------------
+ * F16::from_f32 (:61-98) TRUNCATES the mantissa (no rounding), flushes below 2^-25 to signed zero, maps
+ * overflow to infinity and every NaN to 0x7E00; F16::to_f32 (:101-136) widens exactly (NaN -> 0x7FC00000).
+ * Bf16::from_f32 (:202-206) keeps the upper 16 bits; from_f32_round (:209-220) rounds to nearest even;
+ * to_f32 (:223-225) shifts back. */
+static uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+NDL_API uint16_t ndl_f16_from_f32(float value) {
+    uint32_t bits = f2u(value), sign = (bits >> 31) & 1, mantissa = bits & 0x7FFFFF;
+    int32_t exp = (int32_t)((bits >> 23) & 0xFF);
+    if (exp == 255) return (uint16_t)((sign << 15) | (mantissa == 0 ? 0x7C00 : 0x7E00));
+    int32_t new_exp = exp - 127 + 15;
+    if (new_exp <= 0) {
+        if (new_exp < -10) return (uint16_t)(sign << 15);
+        uint32_t m = (mantissa | 0x800000) >> (1 - new_exp + 13);
+        return (uint16_t)((sign << 15) | m);
+    }
+    if (new_exp >= 31) return (uint16_t)((sign << 15) | 0x7C00);
+    return (uint16_t)((sign << 15) | ((uint32_t)new_exp << 10) | (mantissa >> 13));
+}
+NDL_API float ndl_f16_to_f32(uint16_t h) {
+    uint32_t bits = h, sign = (bits >> 15) & 1, exp = (bits >> 10) & 0x1F, mantissa = bits & 0x3FF;
+    if (exp == 0) {
+        if (mantissa == 0) return u2f(sign << 31);
+        uint32_t m = mantissa; int32_t e = 1;
+        while ((m & 0x400) == 0) { m <<= 1; e -= 1; }
+        return u2f((sign << 31) | ((uint32_t)(127 - 15 + e) << 23) | ((m & 0x3FF) << 13));
+    }
+    if (exp == 31) return u2f((sign << 31) | (mantissa == 0 ? 0x7F800000u : 0x7FC00000u));
+    return u2f((sign << 31) | ((exp - 15 + 127) << 23) | (mantissa << 13));
+}
+NDL_API uint16_t ndl_bf16_from_f32(float value) { return (uint16_t)(f2u(value) >> 16); }
+NDL_API uint16_t ndl_bf16_from_f32_round(float value) {
+    uint32_t bits = f2u(value), round = (bits >> 15) & 1, sticky = (bits & 0x7FFF) != 0;
+    uint16_t upper = (uint16_t)(bits >> 16);
+    return (round != 0 && (sticky || (upper & 1) != 0)) ? (uint16_t)(upper + 1) : upper;
+}
+NDL_API float ndl_bf16_to_f32(uint16_t h) { return u2f((uint32_t)h << 16); }
+/* kind 0 = F16, 1 = Bf16 */
+NDL_API void ndl_half_to_f32(int kind, const uint16_t *in, size_t n, float *out) {
+    for (size_t i = 0; i < n; ++i) out[i] = kind ? ndl_bf16_to_f32(in[i]) : ndl_f16_to_f32(in[i]);
+}
+/* mode 0 = from_f32, 1 = from_f32_round (Bf16 only) */
+NDL_API void ndl_half_from_f32(int kind, int mode, const float *in, size_t n, uint16_t *out) {
+    for (size_t i = 0; i < n; ++i)
+        out[i] = kind ? (mode ? ndl_bf16_from_f32_round(in[i]) : ndl_bf16_from_f32(in[i])) : ndl_f16_from_f32(in[i]);
+}
+
 /* ---- adaptive_search, src/indexing/quantization.rs:890-943 -------------------------------------------
  * Phase 1: the coarse_k = k * max(overfetch, 1) rows nearest over the first `coarse_dims` dimensions
  * (sqrt of euclidean_distance_squared of the truncated slices), by (distance, row) -- the intended set;

@@ -123,6 +123,11 @@ def _declare(L: C.CDLL) -> None:
     L.ndl_sq_batch_search.restype = None
     L.ndl_sq_batch_search.argtypes = [_f32p, sz, sz, _u8p, C.c_uint64, _f32p, _f32p, sz, _u32p, C.c_int, _u64p,
                                       _f32p, _u32p]
+    _u16p = C.POINTER(C.c_uint16)
+    L.ndl_half_to_f32.restype = None
+    L.ndl_half_to_f32.argtypes = [C.c_int, _u16p, sz, _f32p]
+    L.ndl_half_from_f32.restype = None
+    L.ndl_half_from_f32.argtypes = [C.c_int, C.c_int, _f32p, sz, _u16p]
     L.ndl_adaptive_search.restype = sz
     L.ndl_adaptive_search.argtypes = [_f32p, _f32p, C.c_uint64, sz, sz, sz, sz, C.c_int, _u64p, _f32p, _f32p]
     L.ndl_bq_train.restype = None
@@ -595,3 +600,22 @@ def adaptive_search(query, vectors, coarse_dims: int, k: int, overfetch: int, ev
     m = lib().ndl_adaptive_search(_p(q, _f32p), _p(v, _f32p), v.shape[0], v.shape[1], coarse_dims, k, overfetch,
                                   int(evict_nearest), _p(ids, _u64p), _p(full, _f32p), _p(coarse, _f32p))
     return ids[:m], full[:m], coarse[:m]
+
+
+HALF_F16, HALF_BF16 = 0, 1
+
+
+def half_to_f32(kind: int, bits) -> np.ndarray:
+    """F16::to_f32 / Bf16::to_f32 of src/indexing/float16.rs over an array of raw 16-bit patterns."""
+    b = np.ascontiguousarray(bits, dtype=np.uint16)
+    out = np.empty(b.shape, dtype=np.float32)
+    lib().ndl_half_to_f32(kind, b.ctypes.data_as(C.POINTER(C.c_uint16)), b.size, _p(out, _f32p))
+    return out
+
+
+def half_from_f32(kind: int, values, rounded: bool = False) -> np.ndarray:
+    """F16::from_f32 (truncating), Bf16::from_f32 (truncating) or Bf16::from_f32_round."""
+    v = _f32(values)
+    out = np.empty(v.shape, dtype=np.uint16)
+    lib().ndl_half_from_f32(kind, int(rounded), _p(v, _f32p), v.size, out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    return out
