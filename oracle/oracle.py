@@ -1,4 +1,4 @@
-"""ctypes front-end for the CPU oracle (oracle/needle_oracle.c).
+"""ctypes front-end for the CPU oracle (oracle/needle_oracle.c, oracle/needle_hnsw.c).
 
 TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg; the shipped package (needle_amd/) never imports it.
@@ -25,8 +25,8 @@ _u8p = C.POINTER(C.c_uint8)
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc if the shared object is missing or stale."""
-    src = os.path.join(_HERE, "needle_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("needle_oracle.c", "needle_hnsw.c"))
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < newest:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libneedle_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -46,6 +46,7 @@ def lib() -> C.CDLL:
 
 def _declare(L: C.CDLL) -> None:
     sz = C.c_size_t
+    _declare_hnsw(L)
     for name in ("ndl_dot", "ndl_euclidean_squared", "ndl_euclidean", "ndl_cosine", "ndl_cosine_normalized",
                  "ndl_dot_distance", "ndl_manhattan", "ndl_hamming", "ndl_chebyshev", "ndl_dot_chunk4",
                  "ndl_euclidean_chunk4"):
@@ -619,3 +620,99 @@ def half_from_f32(kind: int, values, rounded: bool = False) -> np.ndarray:
     out = np.empty(v.shape, dtype=np.uint16)
     lib().ndl_half_from_f32(kind, int(rounded), _p(v, _f32p), v.size, out.ctypes.data_as(C.POINTER(C.c_uint16)))
     return out
+
+
+def _declare_hnsw(L: C.CDLL) -> None:
+    sz, vp = C.c_size_t, C.c_void_p
+    L.ndl_hnsw_new.restype = vp
+    L.ndl_hnsw_new.argtypes = [_f32p, sz, sz, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64]
+    L.ndl_hnsw_free.restype = None
+    L.ndl_hnsw_free.argtypes = [vp]
+    L.ndl_hnsw_insert.restype = C.c_int
+    L.ndl_hnsw_insert.argtypes = [vp, C.c_uint32]
+    L.ndl_hnsw_insert_range.restype = None
+    L.ndl_hnsw_insert_range.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.ndl_hnsw_delete.restype = C.c_int
+    L.ndl_hnsw_delete.argtypes = [vp, C.c_uint32]
+    L.ndl_hnsw_set_ef_search.restype = None
+    L.ndl_hnsw_set_ef_search.argtypes = [vp, C.c_uint32]
+    L.ndl_hnsw_len.restype = sz
+    L.ndl_hnsw_len.argtypes = [vp]
+    L.ndl_hnsw_entry_level.restype = C.c_uint32
+    L.ndl_hnsw_entry_level.argtypes = [vp]
+    L.ndl_hnsw_degree.restype = sz
+    L.ndl_hnsw_degree.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.ndl_hnsw_search.restype = sz
+    L.ndl_hnsw_search.argtypes = [vp, _f32p, sz, sz, _u64p, _f32p, C.POINTER(sz)]
+    L.ndl_hnsw_batch_search.restype = None
+    L.ndl_hnsw_batch_search.argtypes = [vp, _f32p, sz, sz, _u64p, _f32p, _u32p, C.c_int]
+
+
+class Hnsw:
+    """HnswIndex of src/indexing/hnsw.rs over a fixed row-major vectors array (ids are row numbers), with the
+    reference's default configuration (:249-259) unless overridden.  Levels are drawn from a seeded generator (the
+    reference's are unseeded), so a graph is reproducible here and unpinned against the reference."""
+
+    def __init__(self, vectors, metric: int, m: int = 16, m_max_0: int | None = None, ef_construction: int = 200,
+                 ef_search: int = 50, seed: int = 42):
+        self.vectors = _f32(vectors).reshape(len(vectors), -1) if len(vectors) else np.zeros((0, 1), np.float32)
+        self.ef_search = ef_search
+        self._h = lib().ndl_hnsw_new(_p(self.vectors, _f32p), self.vectors.shape[0], self.vectors.shape[1], metric, m,
+                                     2 * m if m_max_0 is None else m_max_0, ef_construction, ef_search, seed)
+        if not self._h:
+            raise ValueError("invalid HNSW configuration")  # HnswConfig::validate, :326-357
+
+    def insert(self, row: int) -> None:
+        if lib().ndl_hnsw_insert(self._h, row) != 0:
+            raise IndexError(row)
+
+    def insert_range(self, first: int, count: int) -> None:
+        assert 0 <= first and first + count <= self.vectors.shape[0]
+        lib().ndl_hnsw_insert_range(self._h, first, count)
+
+    def delete(self, row: int) -> bool:
+        return bool(lib().ndl_hnsw_delete(self._h, row))
+
+    def set_ef_search(self, ef: int) -> None:
+        """set_ef_search (:566-568)."""
+        self.ef_search = ef
+        lib().ndl_hnsw_set_ef_search(self._h, ef)
+
+    def __len__(self) -> int:
+        return lib().ndl_hnsw_len(self._h)
+
+    @property
+    def entry_level(self) -> int:
+        return lib().ndl_hnsw_entry_level(self._h)
+
+    def degree(self, row: int, layer: int = 0) -> int:
+        return lib().ndl_hnsw_degree(self._h, row, layer)
+
+    def search(self, query, k: int, ef: int | None = None):
+        """search / search_with_ef (:701-771): (ids, distances, visited_nodes)."""
+        q = _f32(query)
+        ids = np.empty(max(k, 1), dtype=np.uint64)
+        dists = np.empty(max(k, 1), dtype=np.float32)
+        vis = C.c_size_t(0)
+        n = lib().ndl_hnsw_search(self._h, _p(q, _f32p), k, self.ef_search if ef is None else ef, _p(ids, _u64p),
+                                  _p(dists, _f32p), C.byref(vis))
+        return ids[:n], dists[:n], vis.value
+
+    def batch_search(self, queries, k: int, threads: int = 1):
+        """Collection::batch_search (src/collection/batch.rs:32-52): [nq, k] ids and distances, counts."""
+        q = _f32(queries)
+        nq = q.shape[0]
+        ids = np.zeros((nq, max(k, 1)), dtype=np.uint64)
+        dists = np.full((nq, max(k, 1)), np.inf, dtype=np.float32)
+        counts = np.zeros(nq, dtype=np.uint32)
+        lib().ndl_hnsw_batch_search(self._h, _p(q, _f32p), nq, k, _p(ids, _u64p), _p(dists, _f32p), _p(counts, _u32p),
+                                    threads)
+        return ids, dists, counts
+
+    def close(self) -> None:
+        if self._h:
+            lib().ndl_hnsw_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()

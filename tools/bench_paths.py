@@ -8,6 +8,9 @@ the configurations BASELINE.json lists (one JSON line per path):
   sq8  SQ8 asymmetric scan over 6.25M x 384 codes (= 50M / 8), 1K queries, k=10
   pq   PQ m=48 table scan over 6.25M x 48 codes (= 50M / 8), 1K queries, k=10
   binary  1-bit codes, Hamming scan over 6.25M x 384 bits (= 50M / 8), 1K queries, k=10
+  hnsw (opt-in: CPU minutes)  what the reference's Collection::batch_search runs today -- its HNSW index at the default
+       configuration, restated on the CPU -- on a bounded sample of the headline workload, with recall@10 against the
+       library's exact result over the same rows and the library's own time beside it
 
 Inputs are synthetic (Gaussian rows; IVF centroids = k-means++ and 8 Lloyd iterations on a 100-rows-per-list sample, trained on the device, quantizer
 parameters trained on a sample; codes of the big sets are drawn uniformly, which is what a scan's
@@ -288,12 +291,47 @@ def binary_case(ctx, dev, n, dim, nq, k, steps, oracle=None):
     ix.close()
 
 
+def hnsw_case(ctx, dev, n, dim, nq, k, threads, oracle):
+    """CPU baseline of the reference's default search path (src/collection/batch.rs:32-52 over src/indexing/hnsw.rs,
+    m = 16, ef_construction = 200, ef_search = 50), restated in oracle/needle_hnsw.c; sequential build as in the
+    reference (insert takes &mut self), searches parallel over the queries."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    base = torch.nn.functional.normalize(torch.randn((n, dim), generator=g, device=dev, dtype=torch.float32), dim=1)
+    queries = torch.nn.functional.normalize(torch.randn((nq, dim), generator=g, device=dev, dtype=torch.float32), dim=1)
+    ix = na.FlatIndex(ctx, base, na.DistanceFunction.Cosine)
+    sec_gpu, out = timed(lambda: search_device(ix._h, queries, k, precision="bf16"), 3, 1)
+    gt = out[0].cpu().numpy()
+    hb, hq = base.cpu().numpy(), queries.cpu().numpy()
+    h = oracle.Hnsw(hb, oracle.COSINE)
+    t0 = time.perf_counter()
+    for first in range(0, n, 2048):  # in pieces, with a progress line: a sequential build of minutes is silent otherwise
+        h.insert_range(first, min(2048, n - first))
+        print(f"hnsw build: {min(first + 2048, n)}/{n} rows, {time.perf_counter() - t0:.0f} s", file=sys.stderr, flush=True)
+    build_s = time.perf_counter() - t0
+    for ef in (50, 200, 800):
+        h.set_ef_search(ef)
+        t0 = time.perf_counter()
+        ids, _, _ = h.batch_search(hq, k, threads=threads)
+        sec = time.perf_counter() - t0
+        recall = float(np.mean([len(set(ids[i].tolist()) & set(gt[i].tolist())) / k for i in range(nq)]))
+        emit("hnsw_cpu", f"reference HNSW (m=16, ef_construction=200, ef_search={ef}) restated on the CPU, {n}x{dim} cosine, k={k}",
+             nq, sec, {"recall_at_k": round(recall, 4), "threads": threads,
+                       "build_s": round(build_s, 1), "build_ms_per_insert": round(build_s / n * 1e3, 3),
+                       "library_exact_ms_same_rows": round(sec_gpu * 1e3, 3), "library_exact_qps_same_rows": round(nq / sec_gpu, 1),
+                       "parity": "graph unpinned (the reference's levels are unseeded); properties pinned by its tests"})
+    h.close()
+    ix.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--paths", default="c1,c5,ivf,sq8,pq,binary")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the row counts (smoke runs)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--hnsw-rows", type=int, default=16384, help="rows of the hnsw path's sample (the build is sequential)")
+    ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--ivf-centroids", default="trained", choices=["trained", "sampled"],
                     help="trained: Lloyd iterations on a sample (balanced lists); sampled: raw rows (hub lists)")
     args = ap.parse_args()
@@ -322,6 +360,10 @@ def main():
         pq_case(ctx, dev, int(6_250_000 * sc), 384, 48, 1000, 10, args.steps, oracle=oracle)
     if "binary" in want:
         binary_case(ctx, dev, int(6_250_000 * sc), 384, 1000, 10, args.steps, oracle=oracle)
+    if "hnsw" in want:
+        if oracle is None:
+            raise SystemExit("the hnsw path is the CPU restatement itself: run without --no-parity")
+        hnsw_case(ctx, dev, args.hnsw_rows, 384, 1000, 10, args.cpu_threads, oracle)
     ctx.close()
 
 
