@@ -296,7 +296,8 @@ needle_hip_status needle_hip_ivf_pq_build(needle_hip_ctx* ctx, const float* base
  * in subspace order.  codes: n x m host bytes (ProductQuantizer::encode output,
  * quantization.rs:377-398); codebooks: [m][256][dim/m] host f32
  * (quantization.rs:322-323).  needle_hip_batch_search on this index returns the
- * k rows nearest by that distance, ties to the lower row id (k <= 256). */
+ * k rows nearest by that distance, ties to the lower row id (k above 256:
+ * every row is scored in the same arithmetic, without the table scan). */
 needle_hip_status needle_hip_pq_build(needle_hip_ctx* ctx, const uint8_t* codes, uint64_t n, uint32_t dim,
                                       uint32_t m, const float* codebooks, const uint32_t* valid_bitmask,
                                       needle_hip_index** out);

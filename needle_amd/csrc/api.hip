@@ -431,8 +431,9 @@ needle_hip_status nh::run_exact(needle_hip_index* ix, const float* d_queries, co
         p.prefix = ix->x_u64.as<uint64_t>();
         p.sel = ix->x_sel.as<uint64_t>();
         p.f = f; p.n = n; p.dim = ix->dim; p.k = k; p.metric = ix->metric; p.arith = ix->arith;
-        if (ix->kind == KIND_IVF && ix->pq_m) {
+        if ((ix->kind == KIND_IVF && ix->pq_m) || ix->kind == KIND_PQ) {
             p.pq_codes = ix->d_codes; p.pq_books = ix->d_codebooks; p.pq_m = ix->pq_m; p.pq_dsub = ix->pq_dsub;
+            p.pq_asym = ix->kind == KIND_IVF;
         }
         if (ix->kind == KIND_SQ8) {
             p.sq_codes = ix->d_codes; p.sq_min = ix->d_sq_min; p.sq_scale = ix->d_sq_scale; p.sq_stride = ix->dpad_f32;

@@ -49,7 +49,13 @@ needle_hip_status nh::pq_search_batch_device(needle_hip_index* ix, const float* 
                                              uint32_t* d_out_counts) {
     needle_hip_ctx* c = ix->ctx;
     const uint32_t n = (uint32_t)ix->n;
-    if (k > KPRIME_MAX) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "k = %u exceeds %d for the quantized scans", k, KPRIME_MAX);
+    if (k > KPRIME_MAX) {  // beyond the per-list budget of the table scan: every row scored in the table's arithmetic
+        ST_TRY(run_exact(ix, d_queries, nullptr, q, k, d_filter, d_out_ids, d_out_dists, d_out_counts));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::lock_guard<std::mutex> g(c->mu);
+        c->m.fallback_queries += q;
+        return NEEDLE_HIP_OK;
+    }
     const uint32_t qg = pq_scan_queries_per_block(ix->pq_m);
     const uint32_t groups = (q + qg - 1) / qg;
     // slices of the code matrix: enough workgroups to fill the chip, slices of >= 4096 rows,

@@ -365,7 +365,7 @@ __device__ inline bool bound_check_sq8(float tau, float dk, double qconst, doubl
 // the arithmetic is the scalar sequence of nh_exact.h continued across the blocks.
 struct RefAcc { float a, b, c; };  // running sums: a = dot | squared distance, b = |q|^2, c = |row|^2
 
-enum RefKind { RK_RS_COS, RK_RS_DOT, RK_RS_L2, RK_C4_COS, RK_C4_DOT, RK_C4_L2, RK_L1, RK_HAMMING, RK_CHEB };
+enum RefKind { RK_RS_COS, RK_RS_DOT, RK_RS_L2, RK_C4_COS, RK_C4_DOT, RK_C4_L2, RK_L1, RK_HAMMING, RK_CHEB, RK_PQ_TABLE };
 
 __device__ inline int ref_kind(int metric, int arith) {
     if (arith == NEEDLE_ARITH_ACCEL_CHUNK4)
@@ -380,10 +380,18 @@ __device__ inline int ref_kind(int metric, int arith) {
     }
 }
 
-// dims [i0, i1) of the vectors, staged at qs[0 .. i1-i0) and bs[0 .. i1-i0); i0 is a multiple of 4
+// dims [i0, i1) of the vectors, staged at qs[0 .. i1-i0) and bs[0 .. i1-i0); i0 is a multiple of 4.
+// RK_PQ_TABLE: `dim` carries the subspace width instead; s.b is the running sum of the current subspace (from -0.0),
+// folded into s.a (from +0.0) at each subspace boundary -- compute_distance_table + distance_with_table,
+// src/indexing/quantization.rs:468-503.
 template <int KIND>
 __device__ inline void ref_accumulate(RefAcc& s, const float* qs, const float* bs, uint32_t i0, uint32_t i1, uint32_t dim) {
-    if (KIND == RK_RS_COS) {  // distance.rs:153-164
+    if (KIND == RK_PQ_TABLE) {
+        for (uint32_t i = 0; i < i1 - i0; ++i) {
+            const float d = qs[i] - bs[i]; const float pd = d * d; s.b = s.b + pd;
+            if ((i0 + i + 1) % dim == 0) { s.a = s.a + s.b; s.b = -0.0f; }
+        }
+    } else if (KIND == RK_RS_COS) {  // distance.rs:153-164
         for (uint32_t i = 0; i < i1 - i0; ++i) {
             const float x = qs[i], y = bs[i];
             const float pxy = x * y; s.a = s.a + pxy;
@@ -455,6 +463,7 @@ __device__ inline float ref_finish(int kind, const RefAcc& s) {
         return 1.0f - (s.a / den);
     }
     case RK_RS_L2:
+    case RK_PQ_TABLE:
     case RK_C4_L2: return sqrtf(s.a);
     default: return s.a;  // caller applies 1 - dot or -dot
     }
@@ -645,13 +654,13 @@ __global__ __launch_bounds__(EX_ROWS) void exact_keys_kernel(ExactParams p) {
         if (live[s] && p.pos_filter) live[s] = bit_set(p.pos_filter + (uint64_t)f * p.pos_filter_words, i);
     }
     const bool sq8 = p.sq_codes != nullptr, pq = p.pq_codes != nullptr;
-    const int kind = (sq8 || pq) ? (int)RK_RS_L2 : ref_kind(p.metric, p.arith);
+    const int kind = (pq && !p.pq_asym) ? (int)RK_PQ_TABLE : ((sq8 || pq) ? (int)RK_RS_L2 : ref_kind(p.metric, p.arith));
     RefAcc acc[EX_SLOTS];
     // Rust's f32 Sum folds from -0.0; the accelerator's sums, the SQ8 and PQ asymmetric sums, the Hamming count and the
     // Chebyshev fold start from +0.0
     const float zero = (sq8 || pq || p.arith == NEEDLE_ARITH_ACCEL_CHUNK4 || kind == RK_HAMMING || kind == RK_CHEB) ? 0.0f : -0.0f;
 #pragma unroll
-    for (int s = 0; s < EX_SLOTS; ++s) { acc[s].a = zero; acc[s].b = zero; acc[s].c = zero; }
+    for (int s = 0; s < EX_SLOTS; ++s) { acc[s].a = zero; acc[s].b = kind == RK_PQ_TABLE ? -0.0f : zero; acc[s].c = zero; }
 
     const uint32_t rows_here = min((uint32_t)EX_ROWS, p.n > row0 ? p.n - row0 : 0u);
     for (uint32_t c0 = 0; c0 < p.dim; c0 += EX_DC) {
@@ -689,6 +698,7 @@ __global__ __launch_bounds__(EX_ROWS) void exact_keys_kernel(ExactParams p) {
         case RK_C4_L2: exact_accumulate_slots<RK_C4_L2>(acc, qs, bs, c0, c0 + len, p.dim, slots); break;
         case RK_L1: exact_accumulate_slots<RK_L1>(acc, qs, bs, c0, c0 + len, p.dim, slots); break;
         case RK_HAMMING: exact_accumulate_slots<RK_HAMMING>(acc, qs, bs, c0, c0 + len, p.dim, slots); break;
+        case RK_PQ_TABLE: exact_accumulate_slots<RK_PQ_TABLE>(acc, qs, bs, c0, c0 + len, p.pq_dsub, slots); break;
         default: exact_accumulate_slots<RK_CHEB>(acc, qs, bs, c0, c0 + len, p.dim, slots); break;
         }
     }

@@ -169,9 +169,10 @@ struct ExactParams {
     const uint32_t* filter;
     const uint32_t* pos2id;   // rows are positions of a list-ordered copy: their row ids (~0 padding), or null
     const uint32_t* pos_filter;  // [f][pos_filter_words] per-slot bitmask over positions, or null
-    const uint8_t* pq_codes;  // product-quantized rows [n][pq_m] scored by asymmetric_distance (IVF-PQ), or null
+    const uint8_t* pq_codes;  // product-quantized rows [n][pq_m], or null
     const float* pq_books;
     uint32_t pq_m, pq_dsub;
+    int pq_asym;              // 1: asymmetric_distance's single accumulator (IVF-PQ); 0: the distance-table sums (PQ index)
     const uint8_t* sq_codes;  // scalar-quantized rows (see PostParams) or null
     const float* sq_min;
     const float* sq_scale;

@@ -75,6 +75,9 @@ def test_pq_masks_ties_and_edges(ctx, oracle):
     for kk in (12, 100, 256):  # bf16: the block of identical codes ties at the top; k = 256 exceeds the candidate budget -> table scan
         _cmp(ix.search(queries, kk, precision="bf16"), opq.batch_search(queries, codes, kk, valid=valid))
     _cmp(ix.search(queries, 12, precision="bf16", filter_mask=filt), opq.batch_search(queries, codes, 12, valid=valid & filt))
+    for kk, prec in ((300, "fp32"), (700, "bf16")):  # k above the table scan's per-list budget: every row scored in the table's arithmetic
+        _cmp(ix.search(queries, kk, precision=prec), opq.batch_search(queries, codes, kk, valid=valid))
+    _cmp(ix.search(queries, 300, filter_mask=filt), opq.batch_search(queries, codes, 300, valid=valid & filt))
     ids, _, counts = ix.search(queries, 0)
     assert ids.shape == (10, 0) and counts.tolist() == [0] * 10
     ix.close()
