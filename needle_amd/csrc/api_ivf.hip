@@ -414,7 +414,11 @@ static needle_hip_status ivf_probe_device(needle_hip_index* ix, const float* d_q
     {
         std::lock_guard<std::mutex> g(ix->centroids->mu);
         // bf16 first pass over the centroids: the probe lists it returns are the exact ones all the same
-        ST_TRY(flat_search_batch_device(ix->centroids, d_queries, q, np, NEEDLE_PRECISION_BF16, nullptr,
+        static const int probe_precision = [] {
+            const char* e = getenv("NEEDLE_HIP_DEBUG_PROBE_FP32");  // development switch
+            return (e && *e == '1') ? NEEDLE_PRECISION_FP32 : NEEDLE_PRECISION_BF16;
+        }();
+        ST_TRY(flat_search_batch_device(ix->centroids, d_queries, q, np, probe_precision, nullptr,
                                         ix->v_probe_ids.as<uint64_t>(), ix->v_probe_d.as<float>(),
                                         ix->v_probe_n.as<uint32_t>()));
     }

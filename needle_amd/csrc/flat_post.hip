@@ -510,9 +510,26 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams
             const uint32_t len = min(dc, p.dim - c0);
             __syncthreads();  // the previous block has been consumed (and spos is visible)
             for (uint32_t i = j; i < len; i += RS_THREADS) qs[i] = qsrc[c0 + i];
-            for (uint32_t r = wave; r < nc; r += RS_THREADS / 64) {
-                const float* src = p.base_raw + (uint64_t)spos[r] * p.dim + c0;
-                for (uint32_t i = lane; i < len; i += 64) rows[r * ld + i] = src[i];
+            // a wave stages rows wave, wave + 4, ...: four rows (eight loads per lane, dc <= 128) are in flight before
+            // the first LDS store, so the gather is bound by bandwidth rather than by one row's latency at a time
+            constexpr uint32_t RS_WAVES = RS_THREADS / 64, RS_UNROLL = 4;
+            for (uint32_t r0 = wave; r0 < nc; r0 += RS_WAVES * RS_UNROLL) {
+                float v[RS_UNROLL][2];
+#pragma unroll
+                for (uint32_t u = 0; u < RS_UNROLL; ++u) {
+                    const uint32_t r = min(r0 + RS_WAVES * u, nc - 1);
+                    const float* src = p.base_raw + (uint64_t)spos[r] * p.dim + c0;
+                    v[u][0] = lane < len ? src[lane] : 0.0f;
+                    v[u][1] = lane + 64 < len ? src[lane + 64] : 0.0f;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < RS_UNROLL; ++u) {
+                    const uint32_t r = r0 + RS_WAVES * u;
+                    if (r < nc) {
+                        if (lane < len) rows[r * ld + lane] = v[u][0];
+                        if (lane + 64 < len) rows[r * ld + lane + 64] = v[u][1];
+                    }
+                }
             }
             __syncthreads();
             if (j < nc) {
