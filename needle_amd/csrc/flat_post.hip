@@ -27,16 +27,22 @@ constexpr uint32_t MERGE_KEYS = 2048 + KPRIME_MAX;
 constexpr uint32_t MERGE_FAST_LISTS = 1024;  // lists per query the one-shot gather handles
 
 // kprime-th largest of keys[0 .. total) (total >= kprime), found bit by bit; all keys are distinct
+// per-lane counts over pairs of keys (a count does not care which lane sees which key), one cross-lane sum per bit
 __device__ inline uint64_t wave_kth_largest_lds(const uint64_t* keys, uint32_t total, uint32_t kprime, uint32_t lane) {
     uint64_t prefix = 0;
+    const uint32_t pairs = total / 2;
+    const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(keys);  // keys is 16-byte aligned
     for (int bit = 63; bit >= 0; --bit) {
         const uint64_t trial = prefix | (1ull << bit);
-        uint32_t cnt = 0;
-        for (uint32_t i = 0; i < total; i += 64) {
-            const bool ge = (i + lane < total) && (keys[i + lane] >= trial);
-            cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ge));
+        uint32_t c = 0;
+        for (uint32_t i = lane; i < pairs; i += 64) {
+            const ulonglong2 v = k2[i];
+            c += (v.x >= trial ? 1u : 0u) + (v.y >= trial ? 1u : 0u);
         }
-        if (cnt >= kprime) prefix = trial;
+        if ((total & 1u) && lane == 0) c += keys[total - 1] >= trial ? 1u : 0u;
+#pragma unroll
+        for (int off = 32; off; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off);
+        if (c >= kprime) prefix = trial;
     }
     return prefix;
 }
@@ -155,7 +161,7 @@ hipError_t launch_merge_select(const PostParams& p, hipStream_t stream) {
 // dense_select: one wave per query over a row of the dense score matrix.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void dense_select_kernel(PostParams p) {
-    extern __shared__ uint32_t ord[];  // [round_up(n, 256)], the tail holds 0
+    extern __shared__ __attribute__((aligned(16))) uint32_t ord[];  // [round_up(n, 256)], the tail holds 0
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
     const uint32_t n4 = (p.n + 255u) & ~255u;
     const float* sc = p.dense_scores + (uint64_t)q * p.dense_ld;
@@ -176,14 +182,16 @@ __global__ __launch_bounds__(64) void dense_select_kernel(PostParams p) {
     if (live > p.kprime) {
         for (int bit = 31; bit >= 0; --bit) {
             const uint32_t trial = kth | (1u << bit);
+            // per-lane counts over four scores per read (a count does not care which lane sees which score; trial > 0
+            // excludes the tail), one cross-lane sum per bit
             uint32_t cnt = 0;
-            for (uint32_t i = 0; i < n4; i += 256) {  // four independent reads per step (trial > 0 excludes the tail)
-                const uint32_t o0 = ord[i + lane], o1 = ord[i + 64 + lane], o2 = ord[i + 128 + lane], o3 = ord[i + 192 + lane];
-                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(o0 >= trial)) +
-                       __builtin_popcountll(__builtin_amdgcn_ballot_w64(o1 >= trial)) +
-                       __builtin_popcountll(__builtin_amdgcn_ballot_w64(o2 >= trial)) +
-                       __builtin_popcountll(__builtin_amdgcn_ballot_w64(o3 >= trial));
+            const uint4* o4 = reinterpret_cast<const uint4*>(ord);
+            for (uint32_t i = 0; i < n4 / 4; i += 64) {
+                const uint4 v = o4[i + lane];
+                cnt += (v.x >= trial ? 1u : 0u) + (v.y >= trial ? 1u : 0u) + (v.z >= trial ? 1u : 0u) + (v.w >= trial ? 1u : 0u);
             }
+#pragma unroll
+            for (int off = 32; off; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
             if (cnt >= p.kprime) kth = trial;
         }
         uint32_t gt = 0;
