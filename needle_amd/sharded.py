@@ -71,6 +71,29 @@ def hip_local_search(index, precision: str = "fp32") -> Callable:
     return run
 
 
+def hip_local_search_handle(handle, nprobe: int = 0, precision: str = "fp32") -> Callable:
+    """local_search bound to any resident index handle (IVF, SQ8, PQ, binary): a shard holds its row block's slice of
+    every inverted list / of the code matrix, with centroids, codebooks and quantizer parameters replicated, so the
+    probe lists are the same on every rank and the union of the shards' candidates is the whole index's."""
+    import ctypes as C
+
+    from . import _lib
+    from .index import PRECISION
+
+    def run(queries: torch.Tensor, k: int):
+        q = queries.shape[0]
+        ids = torch.empty((q, max(k, 1)), dtype=torch.int64, device=queries.device)
+        dists = torch.empty((q, max(k, 1)), dtype=torch.float32, device=queries.device)
+        counts = torch.empty((q,), dtype=torch.int32, device=queries.device)
+        torch.cuda.current_stream(queries.device).synchronize()
+        sp = _lib.SearchParams(k=k, nprobe=nprobe, precision=PRECISION[precision], reserved=0, filter_bitmask=None)
+        _lib.check(_lib.lib().needle_hip_batch_search_device(handle, queries.data_ptr(), q, C.byref(sp), ids.data_ptr(),
+                                                             dists.data_ptr(), counts.data_ptr()))
+        return ids[:, :k], dists[:, :k], counts
+
+    return run
+
+
 def hip_merge(ctx) -> Callable:
     """merge bound to needle_hip_merge_topk_device."""
 
