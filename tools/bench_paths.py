@@ -291,14 +291,20 @@ def binary_case(ctx, dev, n, dim, nq, k, steps, oracle=None):
     ix.close()
 
 
-def hnsw_case(ctx, dev, n, dim, nq, k, threads, oracle):
+def hnsw_case(ctx, dev, n, dim, nq, k, threads, oracle, data="gaussian"):
     """CPU baseline of the reference's default search path (src/collection/batch.rs:32-52 over src/indexing/hnsw.rs,
     m = 16, ef_construction = 200, ef_search = 50), restated in oracle/needle_hnsw.c; sequential build as in the
     reference (insert takes &mut self), searches parallel over the queries."""
     g = torch.Generator(device=dev)
     g.manual_seed(42)
-    base = torch.nn.functional.normalize(torch.randn((n, dim), generator=g, device=dev, dtype=torch.float32), dim=1)
-    queries = torch.nn.functional.normalize(torch.randn((nq, dim), generator=g, device=dev, dtype=torch.float32), dim=1)
+    base = torch.randn((n, dim), generator=g, device=dev, dtype=torch.float32)
+    queries = torch.randn((nq, dim), generator=g, device=dev, dtype=torch.float32)
+    if data == "clustered":  # a mixture of 1000 clusters: the structure real embeddings have and i.i.d. rows lack
+        centres = torch.randn((1000, dim), generator=g, device=dev, dtype=torch.float32)
+        base = centres[torch.randint(0, 1000, (n,), generator=g, device=dev)] + 0.5 * base
+        queries = centres[torch.randint(0, 1000, (nq,), generator=g, device=dev)] + 0.5 * queries
+    base = torch.nn.functional.normalize(base, dim=1).contiguous()
+    queries = torch.nn.functional.normalize(queries, dim=1).contiguous()
     ix = na.FlatIndex(ctx, base, na.DistanceFunction.Cosine)
     sec_gpu, out = timed(lambda: search_device(ix._h, queries, k, precision="bf16"), 3, 1)
     gt = out[0].cpu().numpy()
@@ -315,7 +321,7 @@ def hnsw_case(ctx, dev, n, dim, nq, k, threads, oracle):
         ids, _, _ = h.batch_search(hq, k, threads=threads)
         sec = time.perf_counter() - t0
         recall = float(np.mean([len(set(ids[i].tolist()) & set(gt[i].tolist())) / k for i in range(nq)]))
-        emit("hnsw_cpu", f"reference HNSW (m=16, ef_construction=200, ef_search={ef}) restated on the CPU, {n}x{dim} cosine, k={k}",
+        emit("hnsw_cpu", f"reference HNSW (m=16, ef_construction=200, ef_search={ef}) restated on the CPU, {n}x{dim} cosine ({data} rows), k={k}",
              nq, sec, {"recall_at_k": round(recall, 4), "threads": threads,
                        "build_s": round(build_s, 1), "build_ms_per_insert": round(build_s / n * 1e3, 3),
                        "library_exact_ms_same_rows": round(sec_gpu * 1e3, 3), "library_exact_qps_same_rows": round(nq / sec_gpu, 1),
@@ -332,6 +338,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--hnsw-rows", type=int, default=16384, help="rows of the hnsw path's sample (the build is sequential)")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--hnsw-data", default="gaussian", choices=["gaussian", "clustered"])
     ap.add_argument("--ivf-centroids", default="trained", choices=["trained", "sampled"],
                     help="trained: Lloyd iterations on a sample (balanced lists); sampled: raw rows (hub lists)")
     args = ap.parse_args()
@@ -363,7 +370,7 @@ def main():
     if "hnsw" in want:
         if oracle is None:
             raise SystemExit("the hnsw path is the CPU restatement itself: run without --no-parity")
-        hnsw_case(ctx, dev, args.hnsw_rows, 384, 1000, 10, args.cpu_threads, oracle)
+        hnsw_case(ctx, dev, args.hnsw_rows, 384, 1000, 10, args.cpu_threads, oracle, data=args.hnsw_data)
     ctx.close()
 
 
