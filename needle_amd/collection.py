@@ -7,7 +7,10 @@ ascending by (distance, internal id).
 What differs from the reference on purpose: the reference's `batch_search`
 walks an HNSW graph (approximate); this one is the exact scan that its
 `brute_force_search` / `compute_ground_truth` define, keeping the k NEAREST
-rows (the reference's brute-force heap evicts the nearest).
+rows (the reference's brute-force heap, src/collection/search_methods.rs:189-271,
+is a max-heap keyed the wrong way round for n > k: it evicts the nearest row, a
+behaviour none of its tests pins; the ground-truth routine of
+src/recall_benchmark.rs:183-207 keeps the nearest, and that is what is built here).
 Filters are applied as an exact pre-filter, not as a post-filter of an
 over-fetched candidate list: `Filter` (needle_amd/metadata.py) is evaluated on
 the host into a row bitmask (equality on indexed fields through the inverted
