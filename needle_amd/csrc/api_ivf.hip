@@ -638,7 +638,7 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     sp.item_queries = ix->v_itemq.as<uint2>();
     sp.pos2id = ix->d_pos2id;
     sp.n_queries = q;
-    sp.kseed = std::min<uint32_t>(kprime, (uint32_t)std::min<uint64_t>(k, ix->n) + 6);
+    sp.kseed = std::min<uint32_t>(kprime, (uint32_t)std::min<uint64_t>(k, ix->n));  // rank k: the tightest threshold k sampled rows still reach
     HIP_TRY(ix->w_tau0.ensure((size_t)q * sizeof(float)));
     sp.tau0 = ix->w_tau0.as<float>();
     TauBand band{};
