@@ -542,7 +542,7 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     // lists of any query (bounded by the nprobe longest lists of the index) fit the merge kernel's bookkeeping.
     // Thresholds start from a sample of every query's nearest list (ivf_seed_tau_kernel).  The probe slots are then
     // scanned in up to three launches (by default slots 0-3, then the rest); after each launch a query's threshold
-    // is raised to the (k+6)-th best score it has listed, so the far lists only list what can still matter.
+    // is raised to the k-th best score it has listed, so the far lists only list what can still matter.
     const bool dbg_t = getenv("NEEDLE_HIP_DEBUG") && (atoi(getenv("NEEDLE_HIP_DEBUG")) & 8);
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     if (dbg_t) HIP_TRY(hipStreamSynchronize(c->stream));
