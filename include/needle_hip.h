@@ -363,6 +363,37 @@ needle_hip_status needle_hip_merge_topk_device(needle_hip_ctx* ctx, const float*
                                                uint32_t k, uint64_t* d_out_ids,
                                                float* d_out_dists, uint32_t* d_out_counts);
 
+/* The same merge for host arrays (uploaded, merged on the device, copied back): what
+ * MultiGpuShardManager::search, gpu/mod.rs:1355-1366, does with the per-shard Vecs
+ * it collected, and the chunk merge of streaming_batch_search, gpu/mod.rs:876-892. */
+needle_hip_status needle_hip_merge_topk(needle_hip_ctx* ctx, const float* dists, const uint64_t* ids,
+                                        const uint32_t* counts, uint32_t lists, uint32_t q, uint32_t per,
+                                        uint32_t k, uint64_t* out_ids, float* out_dists, uint32_t* out_counts);
+
+/* normalize, src/distance.rs:426-434 (arith DISTANCE_RS: |v|^2 summed in order, then
+ * every component times 1 / sqrt) and GpuAccelerator::batch_normalize,
+ * gpu/mod.rs:451-473 with normalize_vector_simd, gpu/common.rs:628-635 (arith
+ * ACCEL_CHUNK4: groups of four, every component divided by the norm): n vectors of
+ * `dim` f32 normalised in place; a zero vector is left as it is.  Host pointer /
+ * device pointer. */
+needle_hip_status needle_hip_normalize(needle_hip_ctx* ctx, needle_arith arith, float* vectors, uint64_t n,
+                                       uint32_t dim);
+needle_hip_status needle_hip_normalize_device(needle_hip_ctx* ctx, needle_arith arith, float* d_vectors,
+                                              uint64_t n, uint32_t dim);
+
+/* GpuAccelerator::batch_top_k, gpu/mod.rs:534-549 (stable sort by score, first k) and
+ * partial_sort_top_k, gpu/common.rs:584-626 (heap of k with strict '<', so the
+ * earliest index is kept among equal scores): for each of `rows` score vectors of n
+ * f32 the min(k, n) smallest by (score, index), ascending; -0.0 == +0.0, NaN sorts
+ * last.  Outputs are [rows][k]; unused tails hold index UINT64_MAX / score +inf.
+ * k <= 2048, n < 2^32.  Host pointers / device pointers. */
+needle_hip_status needle_hip_batch_top_k(needle_hip_ctx* ctx, const float* scores, uint32_t rows, uint64_t n,
+                                         uint32_t k, uint64_t* out_idx, float* out_scores,
+                                         uint32_t* out_counts);
+needle_hip_status needle_hip_batch_top_k_device(needle_hip_ctx* ctx, const float* d_scores, uint32_t rows,
+                                                uint64_t n, uint32_t k, uint64_t* d_out_idx,
+                                                float* d_out_scores, uint32_t* d_out_counts);
+
 #ifdef __cplusplus
 }
 #endif

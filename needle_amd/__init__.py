@@ -8,9 +8,9 @@ from . import _lib
 from ._lib import DimensionMismatch, InvalidVector, NeedleHipError
 from .accelerator import GpuAccelerator, GpuResidentIndex
 from .collection import Collection, SearchResult
-from .distance import DistanceFunction, DistanceType
+from .distance import DistanceFunction, DistanceType, normalize, normalized
 from .index import Context, FlatIndex, pack_bitmask
 
 __all__ = ["Collection", "Context", "DimensionMismatch", "DistanceFunction", "DistanceType", "FlatIndex",
            "GpuAccelerator", "GpuResidentIndex", "InvalidVector", "NeedleHipError", "SearchResult", "pack_bitmask",
-           "_lib"]
+           "_lib", "normalize", "normalized"]

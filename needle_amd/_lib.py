@@ -31,6 +31,8 @@ EXPORTS = (
     "needle_hip_batch_distance", "needle_hip_kmeans_assign", "needle_hip_merge_topk_device",
     "needle_hip_ivf_build", "needle_hip_ivf_probe", "needle_hip_ivf_list_sizes", "needle_hip_pq_build",
     "needle_hip_sq8_build", "needle_hip_binary_build", "needle_hip_binary_quantize", "needle_hip_ivf_train", "needle_hip_ivf_pq_build", "needle_hip_flat_build_prefix", "needle_hip_adaptive_search", "needle_hip_pq_train", "needle_hip_pq_encode",
+    "needle_hip_merge_topk", "needle_hip_normalize", "needle_hip_normalize_device", "needle_hip_batch_top_k",
+    "needle_hip_batch_top_k_device",
 )
 
 
@@ -161,6 +163,16 @@ def lib() -> C.CDLL:
     L.needle_hip_binary_build.argtypes = [vp, vp, u64, u32, vp, vp, C.POINTER(vp)]
     L.needle_hip_binary_quantize.restype = i32
     L.needle_hip_binary_quantize.argtypes = [vp, vp, vp, u64, u32, vp]
+    L.needle_hip_merge_topk.restype = i32
+    L.needle_hip_merge_topk.argtypes = [vp, vp, vp, vp, u32, u32, u32, u32, vp, vp, vp]
+    L.needle_hip_normalize.restype = i32
+    L.needle_hip_normalize.argtypes = [vp, i32, vp, u64, u32]
+    L.needle_hip_normalize_device.restype = i32
+    L.needle_hip_normalize_device.argtypes = [vp, i32, vp, u64, u32]
+    L.needle_hip_batch_top_k.restype = i32
+    L.needle_hip_batch_top_k.argtypes = [vp, vp, u32, u64, u32, vp, vp, vp]
+    L.needle_hip_batch_top_k_device.restype = i32
+    L.needle_hip_batch_top_k_device.argtypes = [vp, vp, u32, u64, u32, vp, vp, vp]
     _lib = L
     return L
 

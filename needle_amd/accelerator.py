@@ -59,11 +59,39 @@ class GpuAccelerator:
     # -- streaming_batch_search, gpu/mod.rs:855-903 ---------------------------
     def streaming_batch_search(self, query, vectors, k: int, distance_type: DistanceType,
                                chunk_size: int | None = None) -> List[Hit]:
-        """Chunked search with a global merge.  The device holds the whole base, so the chunking of the
-        reference (a host-memory measure) collapses into one resident search with the same result set."""
-        if len(vectors) == 0:
+        """Chunked search with a global merge: every chunk of `chunk_size` rows (default: the reference's
+        calculate_optimal_chunk_size, gpu/mod.rs:954-973) is searched for its own top k, the per-chunk lists are
+        concatenated with chunk-relative indices made global and merged by (distance, index) on the device
+        (gpu/mod.rs:876-892: concat, stable sort by distance, truncate)."""
+        n = len(vectors)
+        if n == 0:
             return []
-        return self.fused_search(query, vectors, k, distance_type)
+        b = _f32(vectors)
+        if chunk_size is None:
+            # half of the device memory (288 GB) in rows, clamped to [100, 50000] rows
+            chunk_size = int(min(max((144 << 30) // max(b.shape[1] * 4, 1), 100), 50_000))
+        chunk_size = max(int(chunk_size), 1)
+        if n <= chunk_size:
+            return self.fused_search(query, b, k, distance_type)
+        q = _f32(query).reshape(1, -1)
+        starts = list(range(0, n, chunk_size))
+        kk = max(k, 1)
+        ids = np.full((len(starts), 1, kk), np.iinfo(np.uint64).max, dtype=np.uint64)
+        dists = np.full((len(starts), 1, kk), np.inf, dtype=np.float32)
+        counts = np.zeros((len(starts), 1), dtype=np.uint32)
+        metric = DistanceType(distance_type).metric()
+        for c, s in enumerate(starts):
+            ix = FlatIndex(self.ctx, b[s:s + chunk_size], metric, arith=_lib.ARITH_ACCEL_CHUNK4)
+            try:
+                ci, cd, cc = ix.search(q, min(k, min(chunk_size, n - s)))
+            finally:
+                ix.close()
+            m = int(cc[0])
+            ids[c, 0, :m] = ci[0, :m] + np.uint64(s)
+            dists[c, 0, :m] = cd[0, :m]
+            counts[c, 0] = m
+        oi, od, oc = self.ctx.merge_topk(dists, ids, counts, k)
+        return [(int(oi[0, j]), float(od[0, j])) for j in range(int(oc[0]))]
 
     # -- prefiltered_batch_search, gpu/mod.rs:1033-1080 -----------------------
     def prefiltered_batch_search(self, query, vectors: Sequence[Tuple[int, Sequence[float]]], k: int,
@@ -85,6 +113,20 @@ class GpuAccelerator:
         return self.ctx.kmeans_assign(vectors, centroids, _lib.ARITH_ACCEL_CHUNK4).tolist()
 
     # -- batch_top_k, gpu/mod.rs:534-549 --------------------------------------
+    def batch_top_k(self, distances, k: int) -> List[Hit]:
+        """The k smallest of `distances` as (index, distance), ascending; equal distances keep index order."""
+        if len(distances) == 0 or k == 0:
+            return []
+        idx, val, cnt = self.ctx.batch_top_k(_f32(distances).reshape(1, -1), k)
+        return [(int(idx[0, j]), float(val[0, j])) for j in range(int(cnt[0]))]
+
+    # -- batch_normalize, gpu/mod.rs:451-473 ----------------------------------
+    def batch_normalize(self, vectors) -> np.ndarray:
+        """Every vector divided by its norm (normalize_vector_simd, gpu/common.rs:628-635); returns the result."""
+        if len(vectors) == 0:
+            return np.empty((0, 0), dtype=np.float32)
+        return self.ctx.normalize(_f32(vectors), _lib.ARITH_ACCEL_CHUNK4)
+
     def metrics(self) -> dict:
         return self.ctx.metrics()
 

@@ -36,3 +36,22 @@ class DistanceType(enum.IntEnum):
 
     def metric(self) -> DistanceFunction:
         return (DistanceFunction.Cosine, DistanceFunction.Euclidean, DistanceFunction.DotProduct)[int(self)]
+
+
+def normalized(vector, ctx=None):
+    """`normalized` (src/distance.rs:473-477): a unit-length copy of `vector` (a zero vector stays zero), computed on
+    the device in the reference's arithmetic (norm summed in order, every component times 1 / norm)."""
+    from .index import Context
+
+    own = ctx is None
+    c = Context(0) if own else ctx
+    try:
+        return c.normalize(vector)
+    finally:
+        if own:
+            c.close()
+
+
+def normalize(vector, ctx=None) -> None:
+    """`normalize` (src/distance.rs:426-434): in place on a writable float32 numpy array."""
+    vector[...] = normalized(vector, ctx)

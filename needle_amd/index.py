@@ -96,6 +96,47 @@ class Context:
                                                            c.shape[0], v.shape[1], out.ctypes.data))
         return out
 
+    def normalize(self, vectors, arith: int = _lib.ARITH_DISTANCE_RS) -> np.ndarray:
+        """Rows of `vectors` normalised on the device (a copy is returned): distance.rs's `normalize` recipe, or
+        the accelerator's `batch_normalize` with arith ACCEL_CHUNK4."""
+        v = np.array(vectors, dtype=np.float32, order="C", copy=True)
+        flat = v.reshape(1, -1) if v.ndim == 1 else v
+        if flat.size:
+            _lib.check(_lib.lib().needle_hip_normalize(self._h, arith, flat.ctypes.data, flat.shape[0], flat.shape[1]))
+        return v
+
+    def normalize_device(self, d_vectors, arith: int = _lib.ARITH_DISTANCE_RS) -> None:
+        """In place, on a contiguous float32 [n, dim] device tensor."""
+        _lib.check(_lib.lib().needle_hip_normalize_device(self._h, arith, d_vectors.data_ptr(), int(d_vectors.shape[0]),
+                                                          int(d_vectors.shape[1])))
+
+    def batch_top_k(self, scores, k: int):
+        """(idx[rows,k] uint64, scores[rows,k] f32, counts[rows] uint32): the k smallest of every row by (score, index)."""
+        s = _f32(scores)
+        if s.ndim == 1:
+            s = s.reshape(1, -1)
+        rows, n = s.shape
+        kk = max(k, 1)
+        idx = np.full((rows, kk), np.iinfo(np.uint64).max, dtype=np.uint64)
+        val = np.full((rows, kk), np.inf, dtype=np.float32)
+        cnt = np.zeros(rows, dtype=np.uint32)
+        _lib.check(_lib.lib().needle_hip_batch_top_k(self._h, s.ctypes.data if s.size else None, rows, n, k, idx.ctypes.data,
+                                                     val.ctypes.data, cnt.ctypes.data))
+        return idx[:, :k], val[:, :k], cnt
+
+    def merge_topk(self, dists, ids, counts, k: int):
+        """Host form of the shard merge: dists/ids [lists, q, per], counts [lists, q] -> (ids[q,k], dists[q,k], counts[q])."""
+        d, i = _f32(dists), np.ascontiguousarray(ids, dtype=np.uint64)
+        c = np.ascontiguousarray(counts, dtype=np.uint32)
+        lists, q, per = d.shape
+        kk = max(k, 1)
+        oi = np.full((q, kk), np.iinfo(np.uint64).max, dtype=np.uint64)
+        od = np.full((q, kk), np.inf, dtype=np.float32)
+        oc = np.zeros(q, dtype=np.uint32)
+        _lib.check(_lib.lib().needle_hip_merge_topk(self._h, d.ctypes.data, i.ctypes.data, c.ctypes.data, lists, q, per, k,
+                                                    oi.ctypes.data, od.ctypes.data, oc.ctypes.data))
+        return oi[:, :k], od[:, :k], oc
+
     def merge_topk_device(self, d_dists, d_ids, d_counts, lists: int, q: int, per: int, k: int, d_out_ids, d_out_dists,
                           d_out_counts) -> None:
         _lib.check(_lib.lib().needle_hip_merge_topk_device(self._h, d_dists.data_ptr(), d_ids.data_ptr(),

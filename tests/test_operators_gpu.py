@@ -281,3 +281,75 @@ def test_adaptive_search_two_phase(ctx, oracle, shape):
         ix.search_arrays(queries[:, : dim - 1], coarse_dims, k, overfetch)
     assert ix.search_arrays(queries[:3], coarse_dims, 0, overfetch)[3].tolist() == [0, 0, 0]
     ix.close()
+
+
+def test_batch_top_k_reference_kats(accel):
+    """The two value-pinning tests of the reference's selection operators, through the device:
+    batch_top_k (src/experimental/gpu/mod.rs:1669-1679) and partial_sort_top_k (:1964-1972)."""
+    got = accel.batch_top_k([0.5, 0.1, 0.8, 0.3, 0.2], 3)
+    assert [h[0] for h in got] == [1, 4, 3]
+    assert np.array_equal(_bits([h[1] for h in got]), _bits([0.1, 0.2, 0.3]))
+    got = accel.batch_top_k([0.5, 0.1, 0.8, 0.3, 0.2, 0.9, 0.15], 3)
+    assert [h[0] for h in got] == [1, 6, 4]
+    assert accel.batch_top_k([], 3) == [] and accel.batch_top_k([1.0], 0) == []
+    assert [h[0] for h in accel.batch_top_k([2.0, 1.0], 5)] == [1, 0]  # k > n: everything, sorted
+
+
+@pytest.mark.parametrize("shape", [(1, 100, 10), (3, 5000, 1), (2, 70000, 100), (1, 1_000_003, 10), (4, 9000, 2048),
+                                   (1, 300, 300), (2, 4097, 64)])
+def test_batch_top_k_against_oracle(ctx, oracle, shape):
+    rows, n, k = shape
+    rng = np.random.default_rng(rows * 1000 + k)
+    s = rng.standard_normal((rows, n)).astype(F)
+    s[:, ::7] = np.round(s[:, ::7], 1)        # many exact ties, decided by index
+    s[0, 5] = -0.0
+    s[0, 3] = 0.0                              # -0.0 == +0.0: index order
+    s[-1, n // 2:] = s[-1, n // 2]             # a long run of equal scores across block boundaries
+    idx, val, cnt = ctx.batch_top_k(s, k)
+    for r in range(rows):
+        oi, ov = oracle.top_k(s[r], k)
+        assert cnt[r] == oi.size == min(k, n)
+        assert np.array_equal(idx[r, : oi.size], oi), (r, idx[r, :8], oi[:8])
+        assert np.array_equal(_bits(val[r, : oi.size]), _bits(s[r][oi.astype(np.int64)]))
+    inf = np.full((1, 50), np.inf, dtype=F)
+    inf[0, 10] = np.nan                        # NaN sorts behind +inf
+    idx, val, cnt = ctx.batch_top_k(inf, 50)
+    assert idx[0, -1] == 10 and idx[0, :10].tolist() == list(range(10))
+
+
+def test_normalize_reference_kats(ctx, oracle):
+    """normalize (3,4) -> (.6,.8) (src/distance.rs:899-904), zero vector untouched (:1077-1082), and both
+    normalisation recipes bit-equal to the scalar restatement on random rows."""
+    import needle_amd as na
+
+    v = na.normalized([3.0, 4.0], ctx)
+    assert abs(v[0] - 0.6) < 1e-6 and abs(v[1] - 0.8) < 1e-6
+    assert np.all(na.normalized([0.0, 0.0, 0.0], ctx) == 0)
+    w = np.array([3.0, 4.0], dtype=F)
+    na.normalize(w, ctx)
+    assert np.array_equal(_bits(w), _bits(v))
+    rng = np.random.default_rng(11)
+    for dim in (1, 3, 128, 384, 770):
+        rows = (rng.standard_normal((257, dim)) * rng.uniform(1e-3, 1e3, (257, 1))).astype(F)
+        rows[7] = 0.0
+        got = ctx.normalize(rows)
+        want = np.stack([oracle.normalized(r) for r in rows])
+        assert np.array_equal(_bits(got), _bits(want)), dim
+        # the accelerator's recipe: chunk-of-four norm, division (gpu/common.rs:628-635)
+        got4 = ctx.normalize(rows, na._lib.ARITH_ACCEL_CHUNK4)
+        for i in (0, 7, 100, 256):
+            nrm = np.sqrt(F(oracle.accel_batch_distance(rows[i], rows[i:i + 1], oracle.ACCEL_DOT)[0]))
+            want4 = rows[i] / nrm if nrm > 0 else rows[i]
+            assert np.array_equal(_bits(got4[i]), _bits(want4.astype(F))), (dim, i)
+
+
+def test_merge_topk_host(ctx, oracle):
+    rng = np.random.default_rng(15)
+    lists, q, per, k = 3, 20, 8, 6
+    dists = np.sort(rng.random((lists, q, per)).astype(F), axis=2)
+    ids = rng.permutation(lists * q * per).reshape(lists, q, per).astype(np.uint64)
+    counts = rng.integers(0, per + 1, size=(lists, q)).astype(np.uint32)
+    gi, gd, gc = ctx.merge_topk(dists, ids, counts, k)
+    for j in range(q):
+        wi, wd = oracle.merge_topk(dists[:, j, :], ids[:, j, :], counts[:, j], k)
+        assert gc[j] == wi.size and np.array_equal(gi[j, : wi.size], wi) and np.array_equal(_bits(gd[j, : wi.size]), _bits(wd))
