@@ -394,6 +394,22 @@ needle_hip_status needle_hip_batch_top_k_device(needle_hip_ctx* ctx, const float
                                                 uint64_t n, uint32_t k, uint64_t* d_out_idx,
                                                 float* d_out_scores, uint32_t* d_out_counts);
 
+/* needle_hip_batch_top_k_device for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  It has no counterpart in the reference.  Same arguments and
+ * results; the workspace (histograms, per-workgroup tie counts, the selected keys)
+ * lives in a 1 MiB array that is part of the library's code object, one copy per
+ * GPU for the life of the process, so the call issues no hipMalloc / hipFree.
+ * A call whose workspace would exceed 1 MiB (about rows * (8 k + 4 * (260 +
+ * min(ceil(n / 4096), 1024))) bytes) fails with NEEDLE_HIP_ERR_UNSUPPORTED.
+ * Every call on one GPU uses that GPU's one array: calls that overlap in time on
+ * the same GPU (from several contexts or processes' threads) race and must be
+ * serialised by the caller; calls through one context are serialised by it. */
+needle_hip_status needle_hip_batch_top_k_device_noalloc(needle_hip_ctx* ctx, const float* d_scores,
+                                                        uint32_t rows, uint64_t n, uint32_t k,
+                                                        uint64_t* d_out_idx, float* d_out_scores,
+                                                        uint32_t* d_out_counts);
+
 #ifdef __cplusplus
 }
 #endif

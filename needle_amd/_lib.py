@@ -32,7 +32,7 @@ EXPORTS = (
     "needle_hip_ivf_build", "needle_hip_ivf_probe", "needle_hip_ivf_list_sizes", "needle_hip_pq_build",
     "needle_hip_sq8_build", "needle_hip_binary_build", "needle_hip_binary_quantize", "needle_hip_ivf_train", "needle_hip_ivf_pq_build", "needle_hip_flat_build_prefix", "needle_hip_adaptive_search", "needle_hip_pq_train", "needle_hip_pq_encode",
     "needle_hip_merge_topk", "needle_hip_normalize", "needle_hip_normalize_device", "needle_hip_batch_top_k",
-    "needle_hip_batch_top_k_device",
+    "needle_hip_batch_top_k_device", "needle_hip_batch_top_k_device_noalloc",
 )
 
 
@@ -173,6 +173,8 @@ def lib() -> C.CDLL:
     L.needle_hip_batch_top_k.argtypes = [vp, vp, u32, u64, u32, vp, vp, vp]
     L.needle_hip_batch_top_k_device.restype = i32
     L.needle_hip_batch_top_k_device.argtypes = [vp, vp, u32, u64, u32, vp, vp, vp]
+    L.needle_hip_batch_top_k_device_noalloc.restype = i32
+    L.needle_hip_batch_top_k_device_noalloc.argtypes = [vp, vp, u32, u64, u32, vp, vp, vp]
     _lib = L
     return L
 

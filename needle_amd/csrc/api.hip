@@ -93,6 +93,8 @@ extern "C" needle_hip_status needle_hip_init(int device_id, needle_hip_ctx** out
         needle_hip_shutdown(c);
         return fail(NEEDLE_HIP_ERR_HIP, "HIP error %d (%s) creating stream/events", (int)e, hipGetErrorString(e));
     }
+    const needle_hip_status st = topk_static_setup(c);  // device_id is current (hipSetDevice above)
+    if (st != NEEDLE_HIP_OK) { needle_hip_shutdown(c); return st; }
     *out_ctx = c;
     return NEEDLE_HIP_OK;
 }

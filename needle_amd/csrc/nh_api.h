@@ -63,6 +63,8 @@ struct needle_hip_ctx {
     needle_hip_metrics m{};
     std::mutex mu;
     nh::DevBuf scratch[4];  // operator-level calls
+    void* topk_static = nullptr;   // device address of the static top-k workspace on this context's device (ops.hip)
+    size_t topk_static_bytes = 0;
 };
 
 enum IndexKind { KIND_FLAT = 0, KIND_IVF = 1, KIND_PQ = 2, KIND_SQ8 = 3, KIND_BINARY = 4 };
@@ -129,6 +131,8 @@ needle_hip_status run_exact(needle_hip_index* ix, const float* d_queries, const 
 uint32_t choose_kprime(uint32_t k, int precision);
 // builds ix->d_op_bf16 (and ix->bf16_err) on first use; the caller holds ix->mu
 needle_hip_status ensure_bf16_copy(needle_hip_index* ix);
+// takes the device address of the static top-k workspace (ops.hip); the context's device must be current
+needle_hip_status topk_static_setup(needle_hip_ctx* c);
 needle_hip_index* index_new();  // registered as live; null when out of host memory
 void index_free(needle_hip_index* ix);
 needle_hip_status finish_operands(needle_hip_index* ix, bool validate);

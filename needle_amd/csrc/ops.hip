@@ -293,6 +293,49 @@ extern "C" needle_hip_status needle_hip_batch_top_k_device(needle_hip_ctx* c, co
     return NEEDLE_HIP_OK;
 }
 
+// The same operator for callers that cannot allocate (code under HIP graph capture, serving loops, harnesses
+// that forbid hipMalloc): its workspace is this file-scope array, one copy per GPU, held until the process ends.
+// The name below is a host-side stand-in; the device address is taken once per context by
+// topk_static_setup (called from needle_hip_init with the context's device current) and only that pointer is
+// ever handed to kernels and memsets.
+constexpr size_t TOPK_STATIC_BYTES = 1u << 20;
+static __device__ __align__(256) unsigned char scratch[TOPK_STATIC_BYTES];
+
+needle_hip_status nh::topk_static_setup(needle_hip_ctx* c) {
+    void* ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return fail(NEEDLE_HIP_ERR_HIP, "the static top-k workspace has no device address");
+    c->topk_static = ptr;
+    c->topk_static_bytes = TOPK_STATIC_BYTES;
+    return NEEDLE_HIP_OK;
+}
+
+extern "C" needle_hip_status needle_hip_batch_top_k_device_noalloc(needle_hip_ctx* c, const float* d_scores, uint32_t rows,
+                                                                   uint64_t n, uint32_t k, uint64_t* d_out_idx,
+                                                                   float* d_out_scores, uint32_t* d_out_counts) {
+    ST_TRY(topk_check_args(c, d_scores, rows, n, k, d_out_idx, d_out_scores, d_out_counts));
+    if (rows == 0) return NEEDLE_HIP_OK;
+    TopkWork w{};
+    const size_t bytes = (k == 0 || n == 0) ? 0 : topk_work_bytes(rows, n, k, &w);
+    if (bytes > c->topk_static_bytes)
+        return fail(NEEDLE_HIP_ERR_UNSUPPORTED,
+                    "top-k of %u rows x %llu scores at k = %u needs %zu bytes of workspace; the allocation-free entry point "
+                    "holds %zu (use needle_hip_batch_top_k_device, or fewer rows per call)",
+                    rows, (unsigned long long)n, k, bytes, c->topk_static_bytes);
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    if (bytes == 0) {
+        HIP_TRY(launch_fill_empty(d_out_idx, d_out_scores, d_out_counts, rows, k, c->stream));
+    } else {
+        if (!c->topk_static) return fail(NEEDLE_HIP_ERR_HIP, "the static top-k workspace was not set up");
+        // the array keeps the previous call's contents: launch_batch_top_k clears the histograms, everything else
+        // is written before it is read
+        HIP_TRY(launch_batch_top_k(w, c->topk_static, d_scores, d_out_idx, d_out_scores, d_out_counts, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NEEDLE_HIP_OK;
+}
+
 extern "C" needle_hip_status needle_hip_batch_top_k(needle_hip_ctx* c, const float* scores, uint32_t rows, uint64_t n, uint32_t k,
                                                     uint64_t* out_idx, float* out_scores, uint32_t* out_counts) {
     ST_TRY(topk_check_args(c, scores, rows, n, k, out_idx, out_scores, out_counts));
