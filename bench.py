@@ -7,16 +7,21 @@ re-scoring, bound check, exact scan for rejected queries; with more than one GPU
 of per-shard results and the merge).  Inputs are resident in HBM before the timed region starts; the
 index build (upload, norms, operand copy) is outside it, like the reference's insert phase.
 
-Default workload (N=1): exact flat batch_search, 1M x 384 cosine, 10K queries, k=10, synthetic
-unit-normalised Gaussian embeddings, bf16 first pass (the delivered ids and distances are those of
-the reference's f32 scalar arithmetic whatever the first pass; the fp32 first pass is timed beside it).
+--gpus 1 (default): exact flat batch_search, 1M x 384 cosine, 10K queries, k=10, unit-normalised Gaussian
+embeddings, bf16 first pass (the delivered ids and distances are those of the reference's f32 scalar
+arithmetic whatever the first pass; the fp32 first pass is timed beside it).  The JSON line also carries
+`paths`: the other configurations at their per-GPU share (10M x 384 flat, filtered 1M x 768 dot product,
+IVF nlist 4096 / nprobe 32 over 1.25M x 384, SQ8 and PQ m=48 over 6.25M x 384), each with its own roofline
+object, parity sample and host-pointer rate, and the reference's HNSW restated on the CPU over a bounded sample.
 
-With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU):
-  --shard queries (default): every GPU holds the whole base (1M x 384 is 1.5 GB of 288 GB) and serves
-      its own 10K queries; no exchange on the data path; per-GPU work is fixed -> weak scaling.
-  --shard rows: the base is split into N contiguous row blocks, every GPU scans its block for ALL
-      queries, per-shard results are all-gathered over RCCL and merged -> strong scaling of one batch;
-      the layout for bases beyond one GPU's memory.
+--gpus N > 1 (launched by torch.distributed.run, one rank per GPU): the base -- by default 10M x 384 --
+is split into N contiguous row blocks, every GPU scans its block for ALL queries, the per-shard results
+travel in one RCCL all-gather and are merged on every rank (needle_hip_sharded_batch_search_device):
+strong scaling of one batch.  `--shard queries` is the opt-in alternative (every GPU holds the whole base
+and serves its own queries, no exchange).
+
+NEEDLE_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks: ranks
+share devices, the one all-gather goes over gloo and the merge runs through needle_hip_merge_shard_slots_device.
 """
 from __future__ import annotations
 
@@ -36,117 +41,202 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense, MI355X
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense
 GEN_CHUNK = 5000                # rows per generator stream; shard starts are multiples of it
+METRIC_LABEL = "batch-search QPS @ recall@10, 1M & 10M×384 cosine k=10, 1/2/4/8 MI355X"
+DEFAULT_PATHS = "flat10m,c5,ivf,sq8,pq,hnsw"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rows", type=int, default=1_000_000, help="total base rows (split across GPUs)")
+    ap.add_argument("--rows", type=int, default=None,
+                    help="total base rows (default: 1M on one GPU, 10M split across N > 1 GPUs)")
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--queries", type=int, default=10_000)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="cosine")
     ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"])
-    ap.add_argument("--shard", default="queries", choices=["queries", "rows"])
+    ap.add_argument("--shard", default=None, choices=["queries", "rows"],
+                    help="N > 1: rows (default; row blocks, all-gather + merge) or queries (replicas, no exchange)")
     ap.add_argument("--secondary-steps", type=int, default=2, help="steps of the other first-pass precision (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--parity-queries", type=int, default=16, help="N > 1: queries rank 0 checks against the oracle (0 = skip)")
+    ap.add_argument("--paths", default=DEFAULT_PATHS, help="N = 1: other configurations folded into the line ('none' = skip)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per first-pass launch from a separate rocprofv3 --pmc run")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def synth(n, dim, seed, device, first_row=0):
-    """Unit-normalised Gaussian rows; row i depends only on (seed, i), so shards agree with the whole."""
-    out = torch.empty((n, dim), dtype=torch.float32, device=device)
-    chunk = GEN_CHUNK
-    for s in range(0, n, chunk):
-        e = min(n, s + chunk)
-        g = torch.Generator(device=device)
-        g.manual_seed(seed * 1_000_003 + (first_row + s) // chunk)
-        blk = torch.randn((chunk, dim), generator=g, device=device, dtype=torch.float32)
-        blk = blk / blk.norm(dim=1, keepdim=True)
-        off = (first_row + s) % chunk
-        assert off == 0, "shard boundaries must fall on generator chunks"
-        out[s:e] = blk[: e - s]
-    return out
+def generator_seed(seed, first_row):
+    return seed * 1_000_003 + first_row // GEN_CHUNK
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
-    # NEEDLE_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks (ranks
-    # share devices, timing reduced over CPU tensors); the measured runs use RCCL, one rank per GPU.
-    backend = os.environ.get("NEEDLE_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
+class HipBackend:
+    """The product wiring: device tensors, libneedle_hip through the C ABI, RCCL (or a gloo rehearsal) between ranks."""
 
-    import needle_amd as na
-    from needle_amd.sharded import ShardedSearcher, hip_local_search, hip_merge
+    name = "hip"
 
-    chunk = GEN_CHUNK
-    by_rows = args.shard == "rows" and world > 1
-    if by_rows:
-        per = -(-args.rows // world)
-        per = -(-per // chunk) * chunk  # keep shard starts on generator chunks
-        lo = min(rank * per, args.rows)
-        hi = min(lo + per, args.rows)
-    else:
-        lo, hi = 0, args.rows
-    metric = na.DistanceFunction.from_str(args.metric)
+    def __init__(self, rank, local_rank, world):
+        self.rank, self.world = rank, world
+        # gloo: ranks share devices, timing reduced over CPU tensors; the measured runs use RCCL, one rank per GPU
+        self.transport = os.environ.get("NEEDLE_BENCH_BACKEND", "nccl")
+        dev_index = local_rank if self.transport == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(dev_index)
+        self.device = torch.device("cuda", dev_index)
+        if world > 1 and not dist.is_initialized():
+            if self.transport == "nccl":
+                dist.init_process_group("nccl", device_id=self.device)
+            else:
+                dist.init_process_group(self.transport)
+        import needle_amd as na
 
-    base = synth(hi - lo, args.dim, 42, device, first_row=lo)
-    # query-sharded replicas draw different queries per rank; row shards all serve the same ones
-    queries = synth(args.queries, args.dim, 42 + 999_999 + (0 if by_rows else rank), device)
-    torch.cuda.synchronize()
+        self.na = na
+        self.ctx = na.Context(dev_index)
+        self.comm = None
 
-    ctx = na.Context(dev_index)
-    t_build = time.perf_counter()
-    index = na.FlatIndex(ctx, base, metric)
-    t_build = time.perf_counter() - t_build
-    local = {prec: hip_local_search(index, prec) for prec in ("fp32", "bf16")}
-    sharded = {prec: ShardedSearcher(local[prec], hip_merge(ctx), lo) for prec in local} if by_rows else None
-
-    def search(prec):
-        return sharded[prec].search(queries, args.k) if by_rows else local[prec](queries, args.k)
-
-    def barrier():
+    # ---- data -----------------------------------------------------------------------------------
+    def rows(self, n, dim, seed, first_row=0):
+        """Unit-normalised Gaussian rows; row i depends only on (seed, i), so shards agree with the whole.  Normalised with
+        the reference's recipe (src/distance.rs:426-434) by needle_hip_normalize_device."""
+        assert first_row % GEN_CHUNK == 0, "shard boundaries must fall on generator chunks"
+        out = torch.empty((n, dim), dtype=torch.float32, device=self.device)
+        for s in range(0, n, GEN_CHUNK):
+            e = min(n, s + GEN_CHUNK)
+            g = torch.Generator(device=self.device)
+            g.manual_seed(generator_seed(seed, first_row + s))
+            out[s:e] = torch.randn((GEN_CHUNK, dim), generator=g, device=self.device, dtype=torch.float32)[: e - s]
         torch.cuda.synchronize()
-        if world > 1:
+        self.ctx.normalize_device(out)
+        return out
+
+    def host(self, t):
+        return t.cpu().numpy()
+
+    # ---- index and search -------------------------------------------------------------------------
+    def flat_index(self, base, metric):
+        return self.na.FlatIndex(self.ctx, base, metric)
+
+    def searcher(self, index, precision, row_offset, sharded):
+        from needle_amd.sharded import (Communicator, RcclShardedSearcher, ShardedSearcher, hip_local_search, hip_merge)
+
+        if not sharded:
+            return hip_local_search(index, precision)
+        if self.transport == "nccl":
+            if self.comm is None:
+                self.comm = Communicator(self.ctx)
+            return RcclShardedSearcher(index._h, self.comm, row_offset, precision=precision).search
+        return ShardedSearcher(hip_local_search(index, precision), hip_merge(self.ctx), row_offset).search
+
+    def exchange_label(self):
+        return ("one RCCL all-gather behind the C ABI" if self.transport == "nccl"
+                else f"one {self.transport} all-gather (rehearsal), device merge")
+
+    def profile_begin(self):
+        self.ctx.set_profiling(True)
+        self.ctx.reset_metrics()
+
+    def profile_end(self):
+        m = self.ctx.metrics()
+        self.ctx.set_profiling(False)
+        return m
+
+    # ---- ranks ------------------------------------------------------------------------------------
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def barrier(self):
+        torch.cuda.synchronize()
+        if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=self.device if self.transport == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def paths(self, want, oracle):
+        import tools.bench_paths as bp
+
+        return bp.run_paths(self.ctx, self.device, want, steps=2, oracle=oracle)
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+        self.ctx.close()
+        if self.world > 1 and dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def load_oracle():
+    from oracle import oracle as orc  # checker + CPU baseline only; never on the product path
+
+    orc.build()
+    return orc
+
+
+def oracle_sharded_truth(be, orc, args, metric, queries_host, n_shards_rows):
+    """Exact top-k of `queries_host` over the whole base, the oracle scanning one row block at a time (rank 0
+    regenerates every block from the generator) and its merge joining the blocks."""
+    k = args.k
+    per_i, per_d, per_c = [], [], []
+    for lo, hi in n_shards_rows:
+        blk = be.host(be.rows(hi - lo, args.dim, 42, first_row=lo))
+        i, d, c = orc.flat_batch_search(queries_host, blk, k, int(metric), threads=min(orc.cpu_threads(), 16))
+        per_i.append(np.where(i == np.iinfo(np.uint64).max, i, i + np.uint64(lo)))
+        per_d.append(d)
+        per_c.append(c)
+    nq = queries_host.shape[0]
+    oi = np.full((nq, k), np.iinfo(np.uint64).max, dtype=np.uint64)
+    od = np.full((nq, k), np.inf, dtype=np.float32)
+    oc = np.zeros(nq, dtype=np.uint32)
+    for j in range(nq):
+        mi, md = orc.merge_topk(np.stack([d[j] for d in per_d]), np.stack([i[j] for i in per_i]),
+                                np.array([c[j] for c in per_c], dtype=np.uint32), k)
+        oi[j, : mi.size], od[j, : mi.size], oc[j] = mi, md, mi.size
+    return oi, od, oc
+
+
+def run(args, be):
+    """The benchmark's control flow on backend `be`; returns the JSON line on rank 0 (None elsewhere)."""
+    from needle_amd.distance import DistanceFunction
+    from needle_amd.sharded import shard_bounds
+
+    rank, world = be.rank, be.world
+    shard = args.shard or ("rows" if world > 1 else "queries")
+    by_rows = shard == "rows" and world > 1
+    rows_total = args.rows if args.rows is not None else (10_000_000 if by_rows else 1_000_000)
+    spans = [shard_bounds(rows_total, world, r, GEN_CHUNK) for r in range(world)] if by_rows else [(0, rows_total)] * world
+    lo, hi = spans[rank]
+    metric = DistanceFunction.from_str(args.metric)
+
+    base = be.rows(hi - lo, args.dim, 42, first_row=lo)
+    # query-sharded replicas draw different queries per rank; row shards all serve the same ones
+    queries = be.rows(args.queries, args.dim, 42 + 999_999 + (0 if by_rows else rank))
+    be.sync()
+
+    t_build = time.perf_counter()
+    index = be.flat_index(base, metric)
+    t_build = time.perf_counter() - t_build
+    search = {prec: be.searcher(index, prec, lo, by_rows) for prec in ("fp32", "bf16")}
 
     def timed(prec, steps, warmup):
         """(elapsed seconds for `steps` searches, library metrics over them, last result)."""
         out = None
         for _ in range(warmup):
-            out = search(prec)
-        ctx.set_profiling(True)
-        ctx.reset_metrics()
-        barrier()
+            out = search[prec](queries, args.k)
+        be.profile_begin()
+        be.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            out = search(prec)
-        barrier()
+            out = search[prec](queries, args.k)
+        be.barrier()
         el = time.perf_counter() - t0
-        mm = ctx.metrics()
-        ctx.set_profiling(False)
-        if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el, mm, out
+        mm = be.profile_end()
+        return be.max_over_ranks(el), mm, out
 
     def roofline_of(prec, mm):
         # dominant kernel = first-pass scan: algorithmic flops = 2 * Q * rows_local * dim per launch, over the
@@ -177,7 +267,7 @@ def main():
     elapsed, m, out = timed(args.precision, args.steps, args.warmup)
     ids, dists, counts = out
     ms_per_step = elapsed / args.steps * 1e3
-    total_queries = args.queries * (1 if by_rows else world)
+    total_queries = args.queries * (1 if by_rows or world == 1 else world)
     qps = total_queries * args.steps / elapsed
     roofline = roofline_of(args.precision, m)
 
@@ -189,70 +279,98 @@ def main():
                      "unit": "queries/s", "ms_per_step": round(el2 / args.secondary_steps * 1e3, 3),
                      "roofline": roofline_of(other, m2)}
 
-    cpu_baseline = None
-    parity = None
+    cpu_baseline = parity = paths = None
+    orc = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        from oracle import oracle as orc  # checker + CPU baseline only; never on the product path
-
-        orc.build()
+        orc = load_oracle()
         threads = min(orc.cpu_threads(), 16)
-        hb = base.cpu().numpy()
-        hq = queries.cpu().numpy()
+        hb, hq = be.host(base), be.host(queries)
         t1 = time.perf_counter()
         orc.flat_batch_search(hq[:threads], hb, args.k, int(metric), threads=threads)
         one = time.perf_counter() - t1
         rounds = int(max(1, min(16, args.cpu_seconds / max(one, 1e-3) - 1)))
-        nq = min(args.queries - threads, rounds * threads)
+        nq = max(1, min(args.queries - threads, rounds * threads))
         t1 = time.perf_counter()
         oi, od, oc = orc.flat_batch_search(hq[threads:threads + nq], hb, args.k, int(metric), threads=threads)
         dt = time.perf_counter() - t1
         cpu_baseline = {"value": round(nq / dt, 3), "unit": "queries/s", "cores": threads, "kind": "port",
-                        "sample": f"{nq} of the {args.queries} queries against the full {args.rows}x{args.dim} base, "
+                        "flags": "gcc -O2 -ffp-contract=off (no -march=native: the reference's default build is scalar)",
+                        "sample": f"{nq} of the {args.queries} queries against the full {rows_total}x{args.dim} base, "
                                   f"{threads} threads, one query per task (oracle/needle_oracle.c, reference scalar order)"}
-        gi = ids[threads:threads + nq].cpu().numpy().view(np.uint64)
-        gd = dists[threads:threads + nq].cpu().numpy()
+        gi = be.host(ids[threads:threads + nq]).view(np.uint64)
+        gd = be.host(dists[threads:threads + nq])
         parity = {"queries_checked": int(nq), "ids_equal": bool(np.array_equal(gi, oi)),
                   "dists_bit_equal": bool(np.array_equal(gd.view(np.uint32), od.view(np.uint32)))}
-
-    if rank == 0 and world > 1 and not by_rows and args.cpu_seconds > 0:
-        # N > 1: no CPU baseline (timed at N = 1 only), but rank 0 still checks a few of its answers
-        from oracle import oracle as orc  # checker only
-
-        orc.build()
-        nq = min(32, args.queries)
-        oi, od, oc = orc.flat_batch_search(queries[:nq].cpu().numpy(), base.cpu().numpy(), args.k, int(metric),
-                                           threads=min(orc.cpu_threads(), 16))
-        gd = dists[:nq].cpu().numpy()
+        del hb
+    if rank == 0 and world > 1 and args.parity_queries > 0:
+        # N > 1: no CPU baseline (timed at N = 1 only), but rank 0 still checks a few answers against the oracle
+        orc = load_oracle()
+        nq = min(args.parity_queries, args.queries)
+        hq = be.host(queries[:nq])
+        oi, od, oc = oracle_sharded_truth(be, orc, args, metric, hq, spans if by_rows else [(0, rows_total)])
+        gd = be.host(dists[:nq])
         parity = {"queries_checked": int(nq), "rank": 0,
-                  "ids_equal": bool(np.array_equal(ids[:nq].cpu().numpy().view(np.uint64), oi)),
+                  "ids_equal": bool(np.array_equal(be.host(ids[:nq]).view(np.uint64), oi)),
                   "dists_bit_equal": bool(np.array_equal(gd.view(np.uint32), od.view(np.uint32)))}
+    index.close()
+    del base
+    if rank == 0 and world == 1 and args.paths not in ("", "none"):
+        paths = be.paths(args.paths.split(","), orc)
 
+    line = None
     if rank == 0:
+        sharding = (f"row-blocks x{world}, all-gather + merge" if by_rows
+                    else (f"query-sharded replicas x{world}, no exchange" if world > 1 else "single GPU"))
         line = {
-            "metric": "batch-search QPS @ recall@10, 1M & 10M\u00d7384 cosine k=10, 1/2/4/8 MI355X",
+            "metric": METRIC_LABEL,
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong" if by_rows else "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
-            "config": {"workload": f"exact flat batch_search, {args.rows}x{args.dim} {args.metric}, "
+            "config": {"workload": f"exact flat batch_search, {rows_total}x{args.dim} {args.metric}, "
                                    f"{args.queries} queries, k={args.k}, unit-normalised Gaussian embeddings",
-                       "rows_total": args.rows, "rows_per_gpu": hi - lo, "dim": args.dim, "queries": args.queries,
+                       "rows_total": rows_total, "rows_per_gpu": hi - lo, "dim": args.dim, "queries": args.queries,
                        "k": args.k, "first_pass": args.precision, "queries_total": total_queries,
-                       "sharding": (f"row-blocks x{world}, all-gather + merge" if by_rows
-                                    else f"query-sharded replicas x{world}, no exchange"),
+                       "sharding": sharding, "exchange": be.exchange_label() if by_rows else None,
                        "recall_at_10": 1.0 if parity is not None and parity["ids_equal"] else None},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
             "other_first_pass": secondary,
             "refined_queries_per_step": m["refined_queries"] / max(args.steps, 1),
             "fallback_queries_per_step": m["fallback_queries"] / max(args.steps, 1),
             "index_build_s": round(t_build, 3),
+            "paths": paths,
         }
-        print(json.dumps(line))
-    index.close()
-    ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+    return line
+
+
+def parity_ok(line):
+    """False when any parity sample of the line (headline or paths) disagrees with the oracle."""
+    checks = [line.get("parity")] + [p.get("parity") for p in (line.get("paths") or []) if isinstance(p, dict)]
+    for c in checks:
+        if isinstance(c, dict) and not all(v for key, v in c.items() if key.endswith("_equal")):
+            return False
+    return True
+
+
+def main(argv=None, backend=None):
+    args = parse(argv)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    be = backend(rank, local_rank, world) if backend is not None else HipBackend(rank, local_rank, world)
+    try:
+        line = run(args, be)
+    finally:
+        be.close()
+    if line is not None:
+        print(json.dumps(line), flush=True)
+        if not parity_ok(line):
+            print("bench.py: a parity sample disagrees with the oracle", file=sys.stderr)
+            return 3
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -13,6 +13,11 @@
  * src/storage.rs:624-629).  Outputs are written into caller-allocated arrays.
  * Handles are opaque and released by the matching *_destroy / shutdown call.
  *
+ * Streams: every call works on a stream the context owns and returns after its
+ * work completed.  Entry points that take DEVICE pointers do not order
+ * themselves behind the caller's streams: whatever produces those inputs must
+ * have finished (stream or device synchronised) before the call.
+ *
  * Threading: searches on one index serialise on an internal lock (one
  * workspace per index); builds / mask updates need exclusive access, like the
  * reference's &mut self methods.
@@ -39,7 +44,8 @@ typedef enum needle_hip_status {
     NEEDLE_HIP_ERR_HIP = 5,          /* a HIP runtime call failed */
     NEEDLE_HIP_ERR_NOT_TRAINED = 6,  /* IvfError::NotTrained, src/indexing/ivf.rs:79 */
     NEEDLE_HIP_ERR_UNSUPPORTED = 7,
-    NEEDLE_HIP_ERR_NO_DEVICE = 8
+    NEEDLE_HIP_ERR_NO_DEVICE = 8,
+    NEEDLE_HIP_ERR_RCCL = 9          /* an RCCL call failed */
 } needle_hip_status;
 
 /* DistanceFunction, src/distance.rs:43-73 (same order). */
@@ -104,6 +110,8 @@ typedef struct needle_hip_metrics {
     double last_search_ms;        /* device time of the last whole search (profiling on) */
     uint64_t refined_queries;     /* queries a bf16 first pass left undecided, re-run with the fp32 first pass */
     uint64_t binary_code_scans;   /* full passes over a binary code matrix (2 or 3 per batch: see needle_hip_binary_build) */
+    uint64_t list_scans;          /* IVF batches whose inverted-list scan was timed (profiling on) */
+    double list_scan_ms_total;    /* device time of those list scans: threshold sample, list-major scan launches, refreshes */
 } needle_hip_metrics;
 
 /* ---- context --------------------------------------------------------- */
@@ -393,6 +401,47 @@ needle_hip_status needle_hip_batch_top_k(needle_hip_ctx* ctx, const float* score
 needle_hip_status needle_hip_batch_top_k_device(needle_hip_ctx* ctx, const float* d_scores, uint32_t rows,
                                                 uint64_t n, uint32_t k, uint64_t* d_out_idx,
                                                 float* d_out_scores, uint32_t* d_out_counts);
+
+/* ---- row-sharded search over the GPUs of one node --------------------------- */
+
+/* MultiGpuShardManager, src/experimental/gpu/mod.rs:1269-1383, as one process per
+ * GPU: every process builds an index over ITS contiguous block of rows (the
+ * reference places rows round-robin, :1297-1306; contiguous blocks keep
+ * global id = block start + local id, so ties by id survive the merge) and joins
+ * one RCCL communicator.  Rank 0 obtains a unique id, the host distributes its
+ * NEEDLE_HIP_UNIQUE_ID_BYTES bytes over its own channel, every rank calls
+ * needle_hip_comm_init with the same bytes (collective: returns when all joined). */
+#define NEEDLE_HIP_UNIQUE_ID_BYTES 128
+typedef struct needle_hip_comm needle_hip_comm;
+needle_hip_status needle_hip_comm_unique_id(uint8_t* out_id);
+needle_hip_status needle_hip_comm_init(needle_hip_ctx* ctx, const uint8_t* unique_id, int rank, int world,
+                                       needle_hip_comm** out);
+void needle_hip_comm_destroy(needle_hip_comm* comm);
+int needle_hip_comm_rank(const needle_hip_comm* comm);
+int needle_hip_comm_world(const needle_hip_comm* comm);
+
+/* MultiGpuShardManager::search, gpu/mod.rs:1355-1366 (search every shard, concat,
+ * sort by distance, truncate) and merge_shard_results, src/persistence/shard.rs:
+ * 622-643: needle_hip_batch_search_device on this rank's shard, local ids turned
+ * global by adding row_offset, ONE all-gather of the ranks' (ids | distances |
+ * counts) over RCCL / xGMI, and a merge by (distance, global id) on every rank;
+ * all on the context's stream, no host step in between.  Collective: every rank
+ * calls it with the same q, k and queries; every rank receives the full result.
+ * world * k <= 2048.  Device pointers. */
+needle_hip_status needle_hip_sharded_batch_search_device(needle_hip_index* shard, needle_hip_comm* comm,
+                                                         uint64_t row_offset, const float* d_queries,
+                                                         uint32_t q, const needle_search_params* params,
+                                                         uint64_t* d_out_ids, float* d_out_dists,
+                                                         uint32_t* d_out_counts);
+
+/* The merge step of the call above on `lists` slots that another transport
+ * gathered (a host with its own channel between processes; single-GPU rehearsal):
+ * slot l, needle_hip_shard_slot_bytes(q, k) bytes, holds shard l's ids [q][k] u64
+ * (already global), distances [q][k] f32 and counts [q] u32, in that order. */
+uint64_t needle_hip_shard_slot_bytes(uint32_t q, uint32_t k);
+needle_hip_status needle_hip_merge_shard_slots_device(needle_hip_ctx* ctx, const void* d_slots, uint32_t lists,
+                                                      uint32_t q, uint32_t k, uint64_t* d_out_ids,
+                                                      float* d_out_dists, uint32_t* d_out_counts);
 
 /* needle_hip_batch_top_k_device for callers that cannot allocate device memory
  * (code under HIP graph capture, tight serving loops, harnesses that forbid

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NEEDLE_HIP_LIBRARY") or os.path.join(_HERE, "lib", "l
 
 # needle_hip_status
 OK, ERR_DIMENSION_MISMATCH, ERR_INVALID_VECTOR, ERR_INVALID_ARGUMENT, ERR_OUT_OF_MEMORY, ERR_HIP, ERR_NOT_TRAINED, \
-    ERR_UNSUPPORTED, ERR_NO_DEVICE = range(9)
+    ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_RCCL = range(10)
 
 # needle_precision
 PRECISION_FP32, PRECISION_BF16, PRECISION_EXACT_SCAN = range(3)
@@ -33,7 +33,12 @@ EXPORTS = (
     "needle_hip_sq8_build", "needle_hip_binary_build", "needle_hip_binary_quantize", "needle_hip_ivf_train", "needle_hip_ivf_pq_build", "needle_hip_flat_build_prefix", "needle_hip_adaptive_search", "needle_hip_pq_train", "needle_hip_pq_encode",
     "needle_hip_merge_topk", "needle_hip_normalize", "needle_hip_normalize_device", "needle_hip_batch_top_k",
     "needle_hip_batch_top_k_device", "needle_hip_batch_top_k_device_noalloc",
+    "needle_hip_comm_unique_id", "needle_hip_comm_init", "needle_hip_comm_destroy", "needle_hip_comm_rank",
+    "needle_hip_comm_world", "needle_hip_sharded_batch_search_device", "needle_hip_shard_slot_bytes",
+    "needle_hip_merge_shard_slots_device",
 )
+
+UNIQUE_ID_BYTES = 128
 
 
 class SearchParams(C.Structure):
@@ -44,7 +49,8 @@ class SearchParams(C.Structure):
 class Metrics(C.Structure):
     _fields_ = [("searches", C.c_uint64), ("queries", C.c_uint64), ("fallback_queries", C.c_uint64),
                 ("scan_launches", C.c_uint64), ("scan_ms_total", C.c_double), ("last_scan_ms", C.c_double),
-                ("last_search_ms", C.c_double), ("refined_queries", C.c_uint64), ("binary_code_scans", C.c_uint64)]
+                ("last_search_ms", C.c_double), ("refined_queries", C.c_uint64), ("binary_code_scans", C.c_uint64),
+                ("list_scans", C.c_uint64), ("list_scan_ms_total", C.c_double)]
 
 
 class NeedleHipError(RuntimeError):
@@ -175,6 +181,22 @@ def lib() -> C.CDLL:
     L.needle_hip_batch_top_k_device.argtypes = [vp, vp, u32, u64, u32, vp, vp, vp]
     L.needle_hip_batch_top_k_device_noalloc.restype = i32
     L.needle_hip_batch_top_k_device_noalloc.argtypes = [vp, vp, u32, u64, u32, vp, vp, vp]
+    L.needle_hip_comm_unique_id.restype = i32
+    L.needle_hip_comm_unique_id.argtypes = [vp]
+    L.needle_hip_comm_init.restype = i32
+    L.needle_hip_comm_init.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+    L.needle_hip_comm_destroy.restype = None
+    L.needle_hip_comm_destroy.argtypes = [vp]
+    L.needle_hip_comm_rank.restype = i32
+    L.needle_hip_comm_rank.argtypes = [vp]
+    L.needle_hip_comm_world.restype = i32
+    L.needle_hip_comm_world.argtypes = [vp]
+    L.needle_hip_sharded_batch_search_device.restype = i32
+    L.needle_hip_sharded_batch_search_device.argtypes = [vp, vp, u64, vp, u32, C.POINTER(SearchParams), vp, vp, vp]
+    L.needle_hip_shard_slot_bytes.restype = u64
+    L.needle_hip_shard_slot_bytes.argtypes = [u32, u32]
+    L.needle_hip_merge_shard_slots_device.restype = i32
+    L.needle_hip_merge_shard_slots_device.argtypes = [vp, vp, u32, u32, u32, vp, vp, vp]
     _lib = L
     return L
 

@@ -722,9 +722,8 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
         std::lock_guard<std::mutex> g(c->mu);
-        c->m.scan_launches += 1;
-        c->m.scan_ms_total += ms;
-        c->m.last_scan_ms = ms;
+        c->m.list_scans += 1;  // (the probe's own first pass over the centroids is counted under scan_launches)
+        c->m.list_scan_ms_total += ms;
     }
     if (n_flagged > 0) {
         if (n_flagged > q) n_flagged = q;

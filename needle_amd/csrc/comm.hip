@@ -1,0 +1,223 @@
+// Row-sharded search across the GPUs of one node, one process per GPU: every rank searches the same query batch on
+// its own block of rows, the per-rank top-k lists travel in ONE RCCL all-gather over xGMI, and every rank merges them
+// by (distance, global id).  Declarations and reference citations: include/needle_hip.h.
+//
+// Everything is enqueued on the context's stream: local search, id globalisation, all-gather and merge are ordered by
+// the stream, not by the host.
+#include "nh_api.h"
+
+#include <rccl/rccl.h>
+
+using namespace nh;
+
+static_assert(NEEDLE_HIP_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+
+struct needle_hip_comm {
+    needle_hip_ctx* ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    nh::DevBuf gather;  // [world] slots of (ids | dists | counts)
+    std::mutex mu;
+};
+
+#define RCCL_TRY(expr)                                                                                         \
+    do {                                                                                                       \
+        ncclResult_t _r = (expr);                                                                              \
+        if (_r != ncclSuccess)                                                                                 \
+            return nh::fail(NEEDLE_HIP_ERR_RCCL, "RCCL error %d (%s) at %s:%d: %s", (int)_r, ncclGetErrorString(_r), \
+                            __FILE__, __LINE__, #expr);                                                        \
+    } while (0)
+
+namespace nh {
+
+// bytes of one rank's slot: ids [q][k] u64 | dists [q][k] f32 | counts [q] u32, rounded up to 16
+__host__ __device__ inline size_t shard_slot_bytes(uint32_t q, uint32_t k) {
+    return (((size_t)q * k * 12 + (size_t)q * 4) + 15) & ~(size_t)15;
+}
+
+// local row ids -> global ids (padding entries stay UINT64_MAX)
+__global__ __launch_bounds__(256) void shard_globalize_kernel(uint64_t* __restrict__ ids, uint64_t total, uint64_t row_offset) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < total && ids[i] != ~0ull) ids[i] += row_offset;
+}
+
+// One workgroup per query: the `lists` runs of <= per hits (one run per rank, each ascending by (distance, id)) are
+// read from the packed slots, ranked by (distance, id, rank) and the k best emitted; repeated ids keep their best copy
+// (merge_shard_results, src/persistence/shard.rs:622-643).
+__global__ __launch_bounds__(256) void shard_merge_kernel(const unsigned char* __restrict__ slots, size_t slot_bytes, uint32_t lists,
+                                                          uint32_t nq, uint32_t per, uint32_t k, uint64_t* __restrict__ out_ids,
+                                                          float* __restrict__ out_dists, uint32_t* __restrict__ out_counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mraw[];
+    const uint32_t cap = lists * per;
+    uint64_t* sid = (uint64_t*)mraw;
+    uint32_t* sord = (uint32_t*)(sid + cap);
+    uint32_t* sdead = sord + cap;  // 1: empty slot or a worse copy of a repeated id
+    uint32_t* sdup = sdead + cap;
+    __shared__ uint32_t s_kept;
+    const uint32_t q = blockIdx.x;
+    if (threadIdx.x == 0) s_kept = 0;
+    for (uint32_t t = threadIdx.x; t < cap; t += 256) {
+        const uint32_t l = t / per, j = t % per;
+        const unsigned char* slot = slots + (size_t)l * slot_bytes;
+        const uint64_t* ids = (const uint64_t*)slot;
+        const float* dists = (const float*)(slot + (size_t)nq * per * 8);
+        const uint32_t* counts = (const uint32_t*)(slot + (size_t)nq * per * 12);
+        const bool live = j < min(counts[q], per);
+        sid[t] = live ? ids[(size_t)q * per + j] : ~0ull;
+        sord[t] = live ? f2ord(canon_distance(dists[(size_t)q * per + j])) : 0xffffffffu;
+        sdead[t] = live ? 0u : 1u;
+    }
+    __syncthreads();
+    auto before = [&](uint32_t i, uint32_t j) {  // entry i precedes entry j: (distance, id, position)
+        if (sord[i] != sord[j]) return sord[i] < sord[j];
+        if (sid[i] != sid[j]) return sid[i] < sid[j];
+        return i < j;
+    };
+    for (uint32_t j = threadIdx.x; j < cap; j += 256) {
+        uint32_t dup = 0;
+        if (!sdead[j])
+            for (uint32_t i = 0; i < cap; ++i) dup |= (!sdead[i] && i != j && sid[i] == sid[j] && before(i, j)) ? 1u : 0u;
+        sdup[j] = dup;
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < cap; j += 256)
+        if (sdup[j]) sdead[j] = 1u;
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < cap; j += 256) {
+        if (sdead[j]) continue;
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < cap; ++i) rank += (!sdead[i] && i != j && before(i, j)) ? 1u : 0u;
+        atomicAdd(&s_kept, 1u);
+        if (rank < k) {
+            out_ids[(size_t)q * k + rank] = sid[j];
+            out_dists[(size_t)q * k + rank] = ord2f(sord[j]);
+        }
+    }
+    __syncthreads();
+    const uint32_t kept = min(s_kept, k);
+    for (uint32_t r = kept + threadIdx.x; r < k; r += 256) {
+        out_ids[(size_t)q * k + r] = ~0ull;
+        out_dists[(size_t)q * k + r] = INFINITY;
+    }
+    if (threadIdx.x == 0) out_counts[q] = kept;
+}
+
+constexpr uint32_t SHARD_MERGE_MAX_ENTRIES = 2048;  // lists * per of one query (40 KB of LDS)
+
+}  // namespace nh
+
+extern "C" needle_hip_status needle_hip_comm_unique_id(uint8_t* out_id) {
+    if (!out_id) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "out_id is null");
+    ncclUniqueId id;
+    RCCL_TRY(ncclGetUniqueId(&id));
+    memcpy(out_id, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return NEEDLE_HIP_OK;
+}
+
+extern "C" needle_hip_status needle_hip_comm_init(needle_hip_ctx* c, const uint8_t* unique_id, int rank, int world,
+                                                  needle_hip_comm** out) {
+    if (!c || !unique_id || !out) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world)
+        return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "rank %d out of range for %d ranks", rank, world);
+    HIP_TRY(hipSetDevice(c->device));
+    needle_hip_comm* m = new (std::nothrow) needle_hip_comm();
+    if (!m) return fail(NEEDLE_HIP_ERR_OUT_OF_MEMORY, "host allocation failed");
+    m->ctx = c;
+    m->rank = rank;
+    m->world = world;
+    ncclUniqueId id;
+    memcpy(id.internal, unique_id, NCCL_UNIQUE_ID_BYTES);
+    const ncclResult_t r = ncclCommInitRank(&m->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        delete m;
+        return fail(NEEDLE_HIP_ERR_RCCL, "RCCL error %d (%s) in ncclCommInitRank(rank %d of %d)", (int)r, ncclGetErrorString(r), rank,
+                    world);
+    }
+    *out = m;
+    return NEEDLE_HIP_OK;
+}
+
+extern "C" void needle_hip_comm_destroy(needle_hip_comm* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    if (m->comm) (void)ncclCommDestroy(m->comm);
+    m->gather.release();
+    delete m;
+}
+
+extern "C" int needle_hip_comm_rank(const needle_hip_comm* m) { return m ? m->rank : -1; }
+extern "C" int needle_hip_comm_world(const needle_hip_comm* m) { return m ? m->world : 0; }
+
+extern "C" needle_hip_status needle_hip_sharded_batch_search_device(needle_hip_index* ix, needle_hip_comm* m, uint64_t row_offset,
+                                                                    const float* d_queries, uint32_t q,
+                                                                    const needle_search_params* params, uint64_t* d_out_ids,
+                                                                    float* d_out_dists, uint32_t* d_out_counts) {
+    if (!ix || !m || !params) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (ix->ctx != m->ctx) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "the index and the communicator belong to different contexts");
+    if (q == 0) return NEEDLE_HIP_OK;
+    if (!d_queries || !d_out_counts || (params->k > 0 && (!d_out_ids || !d_out_dists)))
+        return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null query or output pointer");
+    needle_hip_ctx* c = m->ctx;
+    const uint32_t k = params->k;
+    std::lock_guard<std::mutex> g(m->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    if (k == 0) {  // nothing to exchange
+        HIP_TRY(launch_fill_empty(d_out_ids, d_out_dists, d_out_counts, q, 0, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return NEEDLE_HIP_OK;
+    }
+    if ((uint64_t)m->world * k > SHARD_MERGE_MAX_ENTRIES)
+        return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "merge of %d shards x k = %u exceeds %u entries per query", m->world, k,
+                    SHARD_MERGE_MAX_ENTRIES);
+    const size_t slot = shard_slot_bytes(q, k);
+    HIP_TRY(m->gather.ensure(slot * (size_t)m->world));
+    unsigned char* mine = m->gather.as<unsigned char>() + slot * (size_t)m->rank;
+    uint64_t* l_ids = (uint64_t*)mine;
+    float* l_dists = (float*)(mine + (size_t)q * k * 8);
+    uint32_t* l_counts = (uint32_t*)(mine + (size_t)q * k * 12);
+    // local top-k of this rank's row block, written straight into its slot of the gather buffer
+    ST_TRY(needle_hip_batch_search_device(ix, d_queries, q, params, l_ids, l_dists, l_counts));
+    const uint64_t total = (uint64_t)q * k;
+    if (row_offset != 0) {
+        hipLaunchKernelGGL(shard_globalize_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, c->stream, l_ids, total,
+                           row_offset);
+        HIP_TRY(hipGetLastError());
+    }
+    // one collective: every rank's slot to every rank (in place: the send buffer is this rank's slot of the receive buffer)
+    RCCL_TRY(ncclAllGather(mine, m->gather.p, slot, ncclChar, m->comm, c->stream));
+    const size_t lds = (size_t)m->world * k * 20;
+    hipLaunchKernelGGL(shard_merge_kernel, dim3(q), dim3(256), lds, c->stream, m->gather.as<unsigned char>(), slot, (uint32_t)m->world,
+                       q, k, k, d_out_ids, d_out_dists, d_out_counts);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NEEDLE_HIP_OK;
+}
+
+// The merge step alone, on slots some other transport filled (tests; hosts that gather over their own channel):
+// d_slots holds `lists` slots of shard_slot_bytes(q, k) bytes each, laid out ids | dists | counts.
+extern "C" needle_hip_status needle_hip_merge_shard_slots_device(needle_hip_ctx* c, const void* d_slots, uint32_t lists, uint32_t q,
+                                                                 uint32_t k, uint64_t* d_out_ids, float* d_out_dists,
+                                                                 uint32_t* d_out_counts) {
+    if (!c) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (q == 0) return NEEDLE_HIP_OK;
+    if (!d_slots || !d_out_counts || lists == 0 || (k > 0 && (!d_out_ids || !d_out_dists)))
+        return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if ((uint64_t)lists * k > SHARD_MERGE_MAX_ENTRIES)
+        return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "merge of %u shards x k = %u exceeds %u entries per query", lists, k,
+                    SHARD_MERGE_MAX_ENTRIES);
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    if (k == 0) {
+        HIP_TRY(launch_fill_empty(d_out_ids, d_out_dists, d_out_counts, q, 0, c->stream));
+    } else {
+        hipLaunchKernelGGL(shard_merge_kernel, dim3(q), dim3(256), (size_t)lists * k * 20, c->stream, (const unsigned char*)d_slots,
+                           shard_slot_bytes(q, k), lists, q, k, k, d_out_ids, d_out_dists, d_out_counts);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NEEDLE_HIP_OK;
+}
+
+extern "C" uint64_t needle_hip_shard_slot_bytes(uint32_t q, uint32_t k) { return shard_slot_bytes(q, k); }

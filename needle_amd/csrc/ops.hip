@@ -11,24 +11,56 @@ using namespace nh;
 // ---------------------------------------------------------------------------
 // normalize
 // ---------------------------------------------------------------------------
-// One thread per row, because the norm is a sequential f32 sum in the reference's order.
+// The norm is a sequential f32 sum in the reference's order, so one thread owns a row's additions; the rows themselves
+// are staged through LDS in pieces of 32 dimensions with coalesced loads (256 rows per workgroup).
 //   DISTANCE_RS : normalize, src/distance.rs:426-434 + 464-469 -- dot folded from -0.0, inv = 1 / sqrt, x * inv
 //   ACCEL_CHUNK4: normalize_vector_simd, src/experimental/gpu/common.rs:628-635 -- groups of four, x / norm
-__global__ __launch_bounds__(256) void normalize_rows_kernel(float* __restrict__ v, uint64_t n, uint32_t dim, int arith) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float* row = v + i * dim;
-    if (arith == NEEDLE_ARITH_ACCEL_CHUNK4) {
-        const float norm = sqrtf(dot_chunk4(row, row, dim));
-        if (norm > 0.0f)
-            for (uint32_t j = 0; j < dim; ++j) row[j] = row[j] / norm;
-    } else {
-        float s = -0.0f;
-        for (uint32_t j = 0; j < dim; ++j) { const float p = row[j] * row[j]; s = s + p; }
-        const float norm = sqrtf(s);
+constexpr int NZ_ROWS = 256, NZ_DC = 32, NZ_LD = NZ_DC + 1;
+__global__ __launch_bounds__(NZ_ROWS) void normalize_rows_kernel(float* __restrict__ v, uint64_t n, uint32_t dim, int arith) {
+    __shared__ float tile[NZ_ROWS][NZ_LD];
+    __shared__ float s_norm[NZ_ROWS];
+    const uint64_t row0 = (uint64_t)blockIdx.x * NZ_ROWS;
+    const uint32_t t = threadIdx.x;
+    const uint32_t rows = (uint32_t)(n - row0 < (uint64_t)NZ_ROWS ? n - row0 : (uint64_t)NZ_ROWS);
+    const bool chunk4 = arith == NEEDLE_ARITH_ACCEL_CHUNK4;
+    const uint32_t dim4 = dim & ~3u;
+    float sum = chunk4 ? 0.0f : -0.0f;
+    for (uint32_t c0 = 0; c0 < dim; c0 += NZ_DC) {
+        const uint32_t w = dim - c0 < (uint32_t)NZ_DC ? dim - c0 : (uint32_t)NZ_DC;
+        for (uint32_t e = t; e < (uint32_t)NZ_ROWS * NZ_DC; e += NZ_ROWS) {
+            const uint32_t r = e / NZ_DC, c = e % NZ_DC;
+            tile[r][c] = (r < rows && c < w) ? v[(row0 + r) * dim + c0 + c] : 0.0f;
+        }
+        __syncthreads();
+        if (t < rows) {
+            if (chunk4) {
+                uint32_t c = 0;
+                for (; c + 4 <= w && c0 + c + 4 <= dim4; c += 4) {
+                    const float p0 = tile[t][c] * tile[t][c], p1 = tile[t][c + 1] * tile[t][c + 1];
+                    const float p2 = tile[t][c + 2] * tile[t][c + 2], p3 = tile[t][c + 3] * tile[t][c + 3];
+                    const float g = ((p0 + p1) + p2) + p3;
+                    sum = sum + g;
+                }
+                for (; c < w; ++c) { const float p = tile[t][c] * tile[t][c]; sum = sum + p; }  // the dim % 4 tail
+            } else {
+                for (uint32_t c = 0; c < w; ++c) { const float p = tile[t][c] * tile[t][c]; sum = sum + p; }
+            }
+        }
+        __syncthreads();
+    }
+    s_norm[t] = sqrtf(sum);
+    __syncthreads();
+    for (uint64_t e = t; e < (uint64_t)rows * dim; e += NZ_ROWS) {
+        const uint32_t r = (uint32_t)(e / dim);
+        const float norm = s_norm[r];
         if (norm > 0.0f) {
-            const float inv = 1.0f / norm;
-            for (uint32_t j = 0; j < dim; ++j) row[j] = row[j] * inv;
+            float* x = v + row0 * dim + e;
+            if (chunk4) {
+                *x = *x / norm;
+            } else {
+                const float inv = 1.0f / norm;
+                *x = *x * inv;
+            }
         }
     }
 }
@@ -45,11 +77,11 @@ extern "C" needle_hip_status needle_hip_normalize_device(needle_hip_ctx* c, need
     ST_TRY(check_arith(arith));
     if (n == 0 || dim == 0) return NEEDLE_HIP_OK;
     if (!d_vectors) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "vectors is null");
-    if ((n + 255) / 256 > 0x7fffffffull) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "too many vectors");
+    if ((n + NZ_ROWS - 1) / NZ_ROWS > 0x7fffffffull) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "too many vectors");
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, d_vectors, n, dim,
-                       (int)arith);
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((uint32_t)((n + NZ_ROWS - 1) / NZ_ROWS)), dim3(NZ_ROWS), 0, c->stream, d_vectors,
+                       n, dim, (int)arith);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     return NEEDLE_HIP_OK;

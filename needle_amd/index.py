@@ -43,6 +43,15 @@ def _mask_words(mask, n):
     return m
 
 
+def _wait_for_producer(t) -> None:
+    """The library works on its own stream: whatever the caller's stream still has in flight for a device tensor must
+    have finished before the library reads it."""
+    if getattr(t, "is_cuda", False):
+        import torch
+
+        torch.cuda.current_stream(t.device).synchronize()
+
+
 class Context:
     """One HIP device (needle_hip_ctx)."""
 
@@ -107,6 +116,7 @@ class Context:
 
     def normalize_device(self, d_vectors, arith: int = _lib.ARITH_DISTANCE_RS) -> None:
         """In place, on a contiguous float32 [n, dim] device tensor."""
+        _wait_for_producer(d_vectors)
         _lib.check(_lib.lib().needle_hip_normalize_device(self._h, arith, d_vectors.data_ptr(), int(d_vectors.shape[0]),
                                                           int(d_vectors.shape[1])))
 
@@ -158,6 +168,7 @@ class FlatIndex:
                 raise ValueError("device base must be a contiguous float32 [n, dim] tensor")
             n, d = int(base.shape[0]), int(base.shape[1])
             vm = _mask_words(valid, n)
+            _wait_for_producer(base)
             _lib.check(L.needle_hip_flat_build_device(ctx._h, base.data_ptr(), n, d, int(self.metric), arith,
                                                       vm.ctypes.data if vm is not None else None, C.byref(self._h)))
         else:
@@ -230,6 +241,7 @@ class FlatIndex:
                       d_filter=None) -> None:
         """Device tensors in and out (float32 [q,dim]; int64/uint64 [q,k]; float32 [q,k]; int32/uint32 [q])."""
         nq = int(d_queries.shape[0])
+        _wait_for_producer(d_queries)
         if int(d_queries.shape[1]) != self.dim:
             raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
                                          f"Dimension mismatch: expected {self.dim}, got {int(d_queries.shape[1])}")

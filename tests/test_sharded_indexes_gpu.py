@@ -1,6 +1,6 @@
 """Row-sharded IVF and SQ8 indexes: every shard holds its row block's slice of the inverted lists / code matrix with the
 centroids / quantizer replicated; the shards' top-k lists, ids shifted to global, merged by (distance, id) through
-needle_hip_merge_topk_device reproduce the whole index's result (the oracle's), bit for bit.  One process plays both
+needle_hip_merge_shard_slots_device (the merge kernel of the RCCL path) reproduce the whole index's result (the oracle's), bit for bit.  One process plays both
 ranks: the exchange itself (all-gather) is covered on CPU by test_sharded_gloo.py."""
 import numpy as np
 import pytest
@@ -22,18 +22,16 @@ def ctx():
 def _merged(ctx, searches, offsets, queries, k):
     import torch
 
-    from needle_amd.sharded import hip_merge
+    from needle_amd.sharded import hip_merge, pack_slot, slot_bytes
 
     dev = torch.device("cuda", 0)
     dq = torch.from_numpy(queries).to(dev)
-    parts = []
-    for run, off in zip(searches, offsets):
+    q = queries.shape[0]
+    slots = torch.zeros((len(searches), slot_bytes(q, k)), dtype=torch.uint8, device=dev)  # what the all-gather delivers
+    for w, (run, off) in enumerate(zip(searches, offsets)):
         ids, dists, counts = run(dq, k)
-        parts.append((torch.where(ids >= 0, ids + off, ids), dists, counts))  # ShardedSearcher.search's shift
-    ai = torch.stack([p[0] for p in parts]).contiguous()
-    ad = torch.stack([p[1] for p in parts]).contiguous()
-    ac = torch.stack([p[2] for p in parts]).contiguous()
-    ids, dists, counts = hip_merge(ctx)(ad, ai, ac, k)
+        pack_slot(slots[w], torch.where(ids >= 0, ids + off, ids), dists, counts)  # ShardedSearcher.search's shift
+    ids, dists, counts = hip_merge(ctx)(slots, len(searches), q, k)
     return ids.cpu().numpy().view(np.uint64), dists.cpu().numpy(), counts.cpu().numpy().view(np.uint32)
 
 
@@ -96,3 +94,32 @@ def test_two_sq8_shards_equal_the_whole_index(ctx, oracle):
     _check(_merged(ctx, runs, offs, queries, k), want)
     for ix in shards:
         ix.close()
+
+
+def test_rccl_entry_point_world_of_one(ctx, oracle):
+    """needle_hip_sharded_batch_search_device with a one-rank RCCL communicator: local search, id offset, the (trivial)
+    all-gather and the merge kernel all run; the result is the shard's own, ids shifted by row_offset."""
+    import torch
+
+    import needle_amd as na
+    from needle_amd.sharded import Communicator, RcclShardedSearcher
+
+    rng = np.random.default_rng(31)
+    base = rng.standard_normal((5000, 72)).astype(F)
+    base[77] = base[5]  # a tie inside the shard
+    queries = rng.standard_normal((130, 72)).astype(F)
+    queries[0] = base[5]
+    ix = na.FlatIndex(ctx, base, na.DistanceFunction.Euclidean)
+    comm = Communicator(ctx)
+    assert comm.world == 1 and comm.rank == 0
+    dq = torch.from_numpy(queries).to(torch.device("cuda", 0))
+    torch.cuda.synchronize()
+    for k, off in ((10, 0), (7, 123_000_000_000), (0, 5)):
+        ids, dists, counts = RcclShardedSearcher(ix._h, comm, off, precision="bf16").search(dq, k)
+        wi, wd, wc = oracle.flat_batch_search(queries, base, k, oracle.EUCLIDEAN)
+        assert np.array_equal(counts.cpu().numpy().view(np.uint32), wc)
+        if k:
+            assert np.array_equal(ids.cpu().numpy().view(np.uint64), wi + np.uint64(off))
+            assert np.array_equal(dists.cpu().numpy().view(np.uint32), wd.view(np.uint32))
+    comm.close()
+    ix.close()

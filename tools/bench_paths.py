@@ -40,6 +40,8 @@ from needle_amd.index import PRECISION, _mask_words  # noqa: E402
 
 F = np.float32
 HBM_PEAK_GBS = 8000.0
+BF16_PEAK_TFLOPS = 2500.0
+FP32_PEAK_TFLOPS = 157.3
 
 
 def search_device(handle, dq, k, *, nprobe=0, precision="fp32", d_filter=None):
@@ -67,28 +69,67 @@ def timed(fn, steps, warmup):
     return (time.perf_counter() - t0) / steps, out
 
 
+COLLECT = None  # a list: entries are appended instead of printed (bench.py folds them into its JSON line)
+
+
 def emit(name, workload, nq, sec, extra):
     line = {"path": name, "workload": workload, "queries": nq, "ms_per_batch": round(sec * 1e3, 3),
             "qps": round(nq / sec, 1)}
     line.update(extra)
-    print(json.dumps(line), flush=True)
+    if COLLECT is not None:
+        COLLECT.append(line)
+    else:
+        print(json.dumps(line), flush=True)
+
+
+def roofline(bound, achieved, unit, kernel, per_unit, launch_ms):
+    """The roofline object of one path: `achieved` = algorithmic bytes or flops of one batch over `launch_ms`."""
+    peak = HBM_PEAK_GBS if bound == "hbm" else (BF16_PEAK_TFLOPS if "bf16" in kernel or "mfma" in kernel else FP32_PEAK_TFLOPS)
+    return {"bound": bound, "kernel": kernel, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+            "frac": round(achieved / peak, 4), "algorithmic": per_unit, "launch_ms": round(launch_ms, 3), "traffic": None}
+
+
+def host_api_qps(handle, queries_host, k, *, nprobe=0, precision="bf16", filt_words=None, reps=2):
+    """The same batch through the host-pointer entry point (pageable numpy buffers: queries up, results down over PCIe)."""
+    q = np.ascontiguousarray(queries_host, dtype=F)
+    nq, dim = q.shape
+    ids = np.empty((nq, k), dtype=np.uint64)
+    dists = np.empty((nq, k), dtype=F)
+    counts = np.empty(nq, dtype=np.uint32)
+    sp = _lib.SearchParams(k=k, nprobe=nprobe, precision=PRECISION[precision], reserved=0,
+                           filter_bitmask=filt_words.ctypes.data if filt_words is not None else None)
+    best = None
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        _lib.check(_lib.lib().needle_hip_batch_search(handle, q.ctypes.data, nq, dim, C.byref(sp), ids.ctypes.data,
+                                                      dists.ctypes.data, counts.ctypes.data))
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return round(nq / best, 1)
 
 
 def bits(a):
     return np.ascontiguousarray(a, dtype=F).view(np.uint32)
 
 
-def flat_case(ctx, dev, name, n, dim, nq, k, metric, steps, filt_frac=None, oracle=None):
+def flat_case(ctx, dev, name, n, dim, nq, k, metric, steps, filt_frac=None, oracle=None, normalise=False, precisions=("bf16", "fp32"),
+              parity_queries=32):
     g = torch.Generator(device=dev)
     g.manual_seed(7)
-    base = torch.randn((n, dim), generator=g, device=dev, dtype=torch.float32)
+    base = torch.empty((n, dim), device=dev, dtype=torch.float32)
+    for s0 in range(0, n, 1 << 20):  # in pieces: randn's temporaries stay small beside a 15 GB base
+        base[s0:s0 + (1 << 20)] = torch.randn((min(1 << 20, n - s0), dim), generator=g, device=dev, dtype=torch.float32)
     queries = torch.randn((nq, dim), generator=g, device=dev, dtype=torch.float32)
+    if normalise:  # "normalized embeddings": the reference's normalize recipe, on the device
+        torch.cuda.synchronize()
+        ctx.normalize_device(base)
+        ctx.normalize_device(queries)
     ix = na.FlatIndex(ctx, base, metric)
     d_filter = keep = None
     if filt_frac:
         keep = (np.random.default_rng(7).random(n) < filt_frac)
         d_filter = torch.from_numpy(_mask_words(keep, n).view(np.int32)).to(dev)
-    for prec in ("bf16", "fp32"):
+    for prec in precisions:
         ctx.set_profiling(True)
         ctx.reset_metrics()
         sec, out = timed(lambda: search_device(ix._h, queries, k, precision=prec, d_filter=d_filter), steps, 1)
@@ -99,10 +140,16 @@ def flat_case(ctx, dev, name, n, dim, nq, k, metric, steps, filt_frac=None, orac
         peak = 2500.0 if prec == "bf16" else 157.3
         extra = {"first_pass": prec, "scan_ms": round(scan_ms, 3), "scan_tflops": round(flops / scan_ms / 1e9, 1),
                  "frac_of_mfma_peak": round(flops / scan_ms / 1e9 / peak, 3),
+                 "roofline": roofline("mfma", flops / scan_ms / 1e9, "TFLOP/s", "flat_scan_" + ("bf16" if prec == "bf16" else "f32"),
+                                      "2*Q*N*D flop per batch", scan_ms),
                  "refined_per_batch": m["refined_queries"] / (steps + 1), "fallback_per_batch": m["fallback_queries"] / (steps + 1)}
+        if prec == precisions[0]:
+            extra["host_pointer_qps"] = host_api_qps(ix._h, queries.cpu().numpy(), k, precision=prec,
+                                                     filt_words=_mask_words(keep, n) if keep is not None else None)
         if oracle is not None:
-            s = min(nq, 32)
-            oi, od, oc = oracle.flat_batch_search(queries[:s].cpu().numpy(), base.cpu().numpy(), k, int(metric), filt=keep)
+            s = min(nq, parity_queries)
+            oi, od, oc = oracle.flat_batch_search(queries[:s].cpu().numpy(), base.cpu().numpy(), k, int(metric), filt=keep,
+                                                  threads=min(oracle.cpu_threads(), 16))
             gi = out[0][:s].cpu().numpy().view(np.uint64)
             extra["parity"] = {"queries_checked": s, "ids_equal": bool(np.array_equal(gi, oi)),
                                "dists_bit_equal": bool(np.array_equal(bits(out[1][:s].cpu().numpy()), bits(od)))}
@@ -119,13 +166,17 @@ def trained_centroids(ctx, sample, nlist, iters, seed=11):
     return ix.centroids, time.perf_counter() - t0
 
 
-def ivf_case(ctx, dev, n, dim, nlist, nprobe, nq, k, steps, oracle=None, centroids="trained"):
+def ivf_case(ctx, dev, n, dim, nlist, nprobe, nq, k, steps, oracle=None, centroids="trained", normalise=True):
     rng = np.random.default_rng(11)
     base = rng.standard_normal((n, dim), dtype=F)
+    if normalise:  # the configuration's "cosine": IvfIndex ranks by Euclidean distance (ivf.rs:67), over unit rows the same order
+        base = ctx.normalize(base)
     cents, train_s = np.ascontiguousarray(base[rng.choice(n, nlist, replace=False)]), 0.0
     if centroids == "trained":  # k-means on a sample of 100 rows per list, as an index is trained
         cents, train_s = trained_centroids(ctx, base[rng.choice(n, min(n, 100 * nlist), replace=False)], nlist, 8)
     queries = rng.standard_normal((nq, dim), dtype=F)
+    if normalise:
+        queries = ctx.normalize(queries)
     h = C.c_void_p()
     t0 = time.perf_counter()
     _lib.check(_lib.lib().needle_hip_ivf_build(ctx._h, base.ctypes.data, n, dim, cents.ctypes.data, nlist, None, None,
@@ -133,7 +184,12 @@ def ivf_case(ctx, dev, n, dim, nlist, nprobe, nq, k, steps, oracle=None, centroi
     build_s = time.perf_counter() - t0
     dq = torch.from_numpy(queries).to(dev)
     sec32, _ = timed(lambda: search_device(h, dq, k, nprobe=nprobe, precision="fp32"), steps, 1)
+    ctx.set_profiling(True)
+    ctx.reset_metrics()
     sec, out = timed(lambda: search_device(h, dq, k, nprobe=nprobe, precision="bf16"), steps, 1)
+    mm = ctx.metrics()
+    ctx.set_profiling(False)
+    list_scan_ms = mm["list_scan_ms_total"] / max(mm["list_scans"], 1)
     sizes = np.zeros(nlist, dtype=np.uint32)
     _lib.check(_lib.lib().needle_hip_ivf_list_sizes(h, sizes.ctypes.data))
     probe = np.full((nq, nprobe), 0xFFFFFFFF, dtype=np.uint32)
@@ -146,7 +202,14 @@ def ivf_case(ctx, dev, n, dim, nlist, nprobe, nq, k, steps, oracle=None, centroi
     bytes_once = int(padded[per_list > 0].sum()) * row_bytes                         # every probed list once
     bytes_unbatched = int((per_list * sizes.astype(np.int64)).sum()) * row_bytes     # per-query scans, as the reference
     pairs = int((per_list * sizes.astype(np.int64)).sum())
-    extra = {"centroids": centroids, "largest_list": int(sizes.max()), "list_scan": "bf16", "fp32_list_scan_ms_per_batch": round(sec32 * 1e3, 3), "build_s": round(build_s, 2), "train_s": round(train_s, 2),
+    bytes_bf16 = bytes_items // 2  # what the bf16 list scan streams (2 bytes per value)
+    extra = {"centroids": centroids, "rows": "unit-normalised Gaussian" if normalise else "Gaussian", "largest_list": int(sizes.max()), "list_scan": "bf16",
+             "list_scan_ms": round(list_scan_ms, 3),
+             "list_scan_only_GBps_f32_rows": round(bytes_items / list_scan_ms / 1e6, 1) if list_scan_ms > 0 else None,
+             "list_scan_only_GBps_bf16_streamed": round(bytes_bf16 / list_scan_ms / 1e6, 1) if list_scan_ms > 0 else None,
+             "roofline": roofline("hbm", bytes_items / sec / 1e9, "GB/s", "ivf list-major scan (whole search)",
+                                  "4*D bytes per row of every probed list, once per tile of the queries probing it", sec * 1e3),
+             "host_pointer_qps": host_api_qps(h, queries, k, nprobe=nprobe, precision="bf16"), "fp32_list_scan_ms_per_batch": round(sec32 * 1e3, 3), "build_s": round(build_s, 2), "train_s": round(train_s, 2),
              "scanned_pairs": pairs,
              "bytes_listmajor": bytes_items, "bytes_each_probed_list_once": bytes_once, "bytes_unbatched": bytes_unbatched,
              "listmajor_GBps_over_whole_search": round(bytes_items / sec / 1e9, 1),
@@ -189,11 +252,16 @@ def sq8_case(ctx, dev, n, dim, nq, k, steps, oracle=None):
         scan_ms = m["scan_ms_total"] / max(m["scan_launches"], 1)
         # every query block streams the operand matrix once: 256 queries x 2-byte operands, or 128 x 1-byte codes
         byts = (-(-nq // 256)) * n * dim * 2 if prec == "bf16" else (-(-nq // 128)) * n * dim
-        extra = {"first_pass": prec, "scan_ms": round(scan_ms, 3), "bytes_scanned": byts,
-                 "scan_GBps": round(byts / scan_ms / 1e6, 1), "frac_of_hbm_peak": round(byts / scan_ms / 1e6 / HBM_PEAK_GBS, 4),
+        algo = (-(-nq // (256 if prec == "bf16" else 128))) * n * dim  # D bytes per vector, once per query block
+        extra = {"first_pass": prec, "scan_ms": round(scan_ms, 3), "bytes_streamed": byts,
+                 "streamed_GBps": round(byts / scan_ms / 1e6, 1),
+                 "roofline": roofline("hbm", algo / scan_ms / 1e6, "GB/s", "sq8 scan, " + prec + " operands",
+                                      "D bytes per vector, once per query block", scan_ms),
                  "scan_tflops": round(2.0 * nq * n * dim / scan_ms / 1e9, 1),
                  "refined_per_batch": m["refined_queries"] / (steps + 1),
                  "fallback_per_batch": m["fallback_queries"] / (steps + 1)}
+        if prec == "bf16":
+            extra["host_pointer_qps"] = host_api_qps(ix._h, queries, k, precision=prec)
         if oracle is not None:
             s, ns = 8, 400_000
             small = na.quantization.Sq8Index(ctx, sq, codes[:ns])
@@ -207,7 +275,7 @@ def sq8_case(ctx, dev, n, dim, nq, k, steps, oracle=None):
     ix.close()
 
 
-def pq_case(ctx, dev, n, dim, m_sub, nq, k, steps, oracle=None):
+def pq_case(ctx, dev, n, dim, m_sub, nq, k, steps, oracle=None, build_timing=True):
     rng = np.random.default_rng(17)
     books = rng.standard_normal((m_sub, 256, dim // m_sub), dtype=F)
     pq = na.quantization.ProductQuantizer(books)
@@ -228,6 +296,9 @@ def pq_case(ctx, dev, n, dim, m_sub, nq, k, steps, oracle=None):
                      "scan_ms": round(scan_ms, 3), "bytes_scanned": byts, "scan_GBps": round(byts / scan_ms / 1e6, 1),
                      "frac_of_hbm_peak": round(byts / scan_ms / 1e6 / HBM_PEAK_GBS, 4),
                      "scan_tflops": round(2.0 * nq * n * dim / scan_ms / 1e9, 1),
+                     "roofline": roofline("hbm", (-(-nq // 256)) * n * m_sub / scan_ms / 1e6, "GB/s", "pq: bf16 scan of the decoded rows",
+                                          "m bytes per vector, once per query block (the route streams 2*D bytes of decoded row instead)", scan_ms),
+                     "host_pointer_qps": host_api_qps(ix._h, queries, k, precision=prec),
                      "fallback_per_batch": mm["fallback_queries"] / (steps + 1)}
         else:
             qg = min(3, (150 * 1024) // (m_sub * 1024))
@@ -235,6 +306,8 @@ def pq_case(ctx, dev, n, dim, m_sub, nq, k, steps, oracle=None):
             extra = {"first_pass": "f32 distance-table scan", "queries_per_workgroup": qg, "bytes_scanned": byts,
                      "GBps_over_whole_search": round(byts / sec / 1e9, 1),
                      "frac_of_hbm_peak": round(byts / sec / 1e9 / HBM_PEAK_GBS, 4),
+                     "roofline": roofline("hbm", byts / sec / 1e9, "GB/s", "pq_scan_kernel (distance tables in LDS)",
+                                          "m bytes per vector, once per query group", sec * 1e3),
                      "table_lookups_per_s": round(nq * n * m_sub / sec / 1e12, 3)}
         if oracle is not None:
             s, ns = 6, 500_000
@@ -247,6 +320,8 @@ def pq_case(ctx, dev, n, dim, m_sub, nq, k, steps, oracle=None):
             small.close()
         emit("pq", f"PQ m={m_sub} asymmetric scan over {n}x{m_sub} codes (dim {dim}), k={k}", nq, sec, extra)
     ix.close()
+    if not build_timing:
+        return
     # codebook training and encoding on the device (Gaussian rows; the scans above use random codes and books)
     sample = rng.standard_normal((65536, dim), dtype=F)
     t0 = time.perf_counter()
@@ -255,8 +330,12 @@ def pq_case(ctx, dev, n, dim, m_sub, nq, k, steps, oracle=None):
     rows = rng.standard_normal((min(n, 1_000_000), dim), dtype=F)
     t0 = time.perf_counter()
     tpq.encode_device(ctx, rows)
-    print(json.dumps({"path": "pq_build", "train_s_65536_rows": round(train_s, 2),
-                      "encode_rows_per_s_incl_pcie": round(rows.shape[0] / (time.perf_counter() - t0), 1)}), flush=True)
+    line = {"path": "pq_build", "train_s_65536_rows": round(train_s, 2),
+            "encode_rows_per_s_incl_pcie": round(rows.shape[0] / (time.perf_counter() - t0), 1)}
+    if COLLECT is not None:
+        COLLECT.append(line)
+    else:
+        print(json.dumps(line), flush=True)
 
 
 def binary_case(ctx, dev, n, dim, nq, k, steps, oracle=None):
@@ -328,6 +407,35 @@ def hnsw_case(ctx, dev, n, dim, nq, k, threads, oracle, data="gaussian"):
                        "parity": "graph unpinned (the reference's levels are unseeded); properties pinned by its tests"})
     h.close()
     ix.close()
+
+
+def run_paths(ctx, dev, want, steps=2, oracle=None, scale=1.0, hnsw_rows=8192, cpu_threads=16):
+    """The legs bench.py folds into its JSON line (`paths`): every entry carries its own roofline object computed
+    from algorithmic bytes / flops, a parity sample against the oracle and the host-pointer (PCIe-inclusive) rate."""
+    global COLLECT
+    COLLECT = []
+    sc = scale
+    try:
+        if "flat10m" in want:
+            flat_case(ctx, dev, "flat10m", int(10_000_000 * sc), 384, 10_000, 10, na.DistanceFunction.Cosine, steps, oracle=oracle,
+                      normalise=True, precisions=("bf16",), parity_queries=16)
+        if "c1" in want:
+            flat_case(ctx, dev, "c1", int(100_000 * sc), 128, 1000, 10, na.DistanceFunction.Euclidean, steps, oracle=oracle,
+                      precisions=("bf16",))
+        if "c5" in want:
+            flat_case(ctx, dev, "c5", int(1_000_000 * sc), 768, 1000, 100, na.DistanceFunction.DotProduct, steps, filt_frac=0.1,
+                      oracle=oracle, precisions=("bf16",), parity_queries=16)
+        if "ivf" in want:
+            ivf_case(ctx, dev, int(1_250_000 * sc), 384, max(16, int(4096 * sc)), 32, 10_000, 10, steps, oracle=oracle)
+        if "sq8" in want:
+            sq8_case(ctx, dev, int(6_250_000 * sc), 384, 1000, 10, steps, oracle=oracle)
+        if "pq" in want:
+            pq_case(ctx, dev, int(6_250_000 * sc), 384, 48, 1000, 10, steps, oracle=oracle, build_timing=False)
+        if "hnsw" in want and oracle is not None:
+            hnsw_case(ctx, dev, hnsw_rows, 384, 1000, 10, cpu_threads, oracle)
+        return COLLECT
+    finally:
+        COLLECT = None
 
 
 def main():
