@@ -544,7 +544,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     const uint32_t q_pad = round_up(q, q_block), q_tiles = q_pad / q_block;
     const uint32_t n_tiles = ix->n_pad / TILE_ROWS;
     const uint32_t cap = list_cap(kprime);
-    const uint32_t lists_per_split = bf16 ? 2 : 1;  // bf16: one list per lane half
+    const uint32_t lists_per_split = bf16 ? flat_scan_bf16_lists_per_slice() : 1;  // bf16: one list per lane group
     // the merge holds a query's lists in LDS: lists * kprime keys of 8 bytes within 64 KB
     const uint32_t max_splits = std::max<uint32_t>(1, 8192u / (kprime * lists_per_split));
     SplitPlan plan = plan_splits(q_tiles, n_tiles, (uint32_t)c->n_cu * (uint32_t)flat_scan_blocks_per_cu(precision), max_splits);

@@ -523,7 +523,7 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     bool bf16 = (precision == NEEDLE_PRECISION_BF16 || pq) && flat_scan_bf16_dpad(ix->dim) != 0;
     if (bf16 && choose_kprime((uint32_t)std::min<uint64_t>(k, ix->n), NEEDLE_PRECISION_BF16) > KPRIME_MAX) bf16 = false;
     const int scan_precision = bf16 ? NEEDLE_PRECISION_BF16 : NEEDLE_PRECISION_FP32;
-    const uint32_t lpe = bf16 ? 2 : 1;  // candidate lists per (query, list run): the bf16 kernel keeps one per lane half
+    const uint32_t lpe = bf16 ? flat_scan_bf16_lists_per_slice() : 1;  // candidate lists per (query, list run): the bf16 kernel keeps one per lane group
     const uint32_t kprime = choose_kprime((uint32_t)std::min<uint64_t>(k, ix->n), scan_precision);
     const bool exact_only = precision == NEEDLE_PRECISION_EXACT_SCAN || kprime > KPRIME_MAX || (pq && !bf16);
     if (exact_only) {

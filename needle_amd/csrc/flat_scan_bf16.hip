@@ -46,6 +46,9 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #ifndef BF_FILL_SPREAD
 #define BF_FILL_SPREAD 1  // 1: one fill piece per k-step from BF_FILL_KK on; 0: all four at BF_FILL_KK
 #endif
+#ifndef BF_STAGGER
+#define BF_STAGGER 0      // 1: eight-wave workgroups hold waves 4-7 half a stage behind waves 0-3 (measured 1-2 % slower)
+#endif
 #ifndef BF_READ_AHEAD
 #define BF_READ_AHEAD 2   // fragment reads run this many k-steps ahead of the MFMAs (2 or 3)
 #endif
@@ -107,21 +110,21 @@ __device__ inline void push_lane(const f32x16& acc, uint32_t row_base, uint32_t 
 }
 
 // direct-to-LDS loads a wave issues for stage u of a tile (u = half * STAGES + s, taken modulo the tile)
-template <int STAGES, bool CINIT>
-constexpr int bf_stage_loads(int u) { return 4 + ((CINIT && (u % STAGES) == 0) ? 1 : 0); }
+template <int STAGES, bool CINIT, int PIECES = 4>
+constexpr int bf_stage_loads(int u) { return PIECES + ((CINIT && (u % STAGES) == 0) ? 1 : 0); }
 // loads issued behind stage u that may still be in flight when stage u is awaited
 // loads that may stay in flight while stage u + 1 is awaited at the fill point of stage u: those of stages
 // u + 2 .. u + BF_PD - 1 (stage u + BF_PD is issued right behind that wait)
-template <int STAGES, bool CINIT>
+template <int STAGES, bool CINIT, int PIECES = 4>
 constexpr int bf_steady_inflight(int u) {
     int n = 0;
-    for (int j = 2; j < BF_PD; ++j) n += bf_stage_loads<STAGES, CINIT>(u + j);
+    for (int j = 2; j < BF_PD; ++j) n += bf_stage_loads<STAGES, CINIT, PIECES>(u + j);
     return n;
 }
-template <int STAGES, bool CINIT>
+template <int STAGES, bool CINIT, int PIECES = 4>
 constexpr int bf_inflight_behind(int u) {
     int n = 0;
-    for (int j = 1; j < BF_PD; ++j) n += bf_stage_loads<STAGES, CINIT>(u + j);
+    for (int j = 1; j < BF_PD; ++j) n += bf_stage_loads<STAGES, CINIT, PIECES>(u + j);
     return n;
 }
 
@@ -412,6 +415,325 @@ __global__ __launch_bounds__(256, 1) void flat_scan_bf16_kernel(ScanParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same scan on v_mfma_f32_16x16x32_bf16.  Cycles per flop, LDS traffic and register budget equal the 32x32x16
+// form's (per 32 dimensions: 4 fragment reads feed 4 x NTQ MFMAs of 16 cycles), but on random operands the chip holds
+// a higher clock under this shape.
+//   * a wave multiplies the 64 staged rows (4 row tiles of 16) with its 16 * NTQ queries (NTQ query tiles of 16);
+//   * lane (l15 = lane & 15, quad = lane >> 4) holds, of query tile t, dims 32 ks + 8 quad .. +7 of query
+//     q0 + 16 t + l15 (B operand) and reads dims 8 quad .. +7 of k-step ks of row 16 mt + l15 (A operand):
+//     logical chunk 4 ks + quad of the row, at physical chunk (4 ks + quad) ^ l15 -- the 16 lanes of every
+//     ds_read_b128 phase land on 16 different chunk positions, i.e. all 64 banks;
+//   * result register r of tile (mt, t) is row 16 mt + 4 quad + r against the lane's query of tile t: column = lane,
+//     as before, so thresholds stay per-lane registers; the four quads of a query keep a candidate list each.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__device__ inline void push_lane16(const f32x4 (&acc)[4], uint32_t row_base, uint32_t quad, uint32_t lane, const ScanParams& p,
+                                   uint32_t list_idx, float& tau, uint32_t& cnt) {
+    float gm[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) gm[mt] = fmaxf(fmaxf(acc[mt][0], acc[mt][1]), fmaxf(acc[mt][2], acc[mt][3]));
+    const float m = fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3]));
+    if (__builtin_amdgcn_ballot_w64(m > tau) == 0) return;  // wave-uniform
+    uint2* mylist = p.lists + (uint64_t)list_idx * p.cap;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        if (gm[mt] > tau) {  // rows 16 mt + 4 quad .. + 3 of the half tile
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float key = acc[mt][j];
+                if (key > tau) {
+                    const uint32_t row = row_base + 16 * mt + 4 * quad + j;
+                    if (row_live<MODE>(p, row)) {
+                        mylist[cnt] = make_uint2(__float_as_uint(key), row);
+                        cnt += 1;
+                    }
+                }
+            }
+        }
+    }
+    uint64_t need = __builtin_amdgcn_ballot_w64(cnt > p.cap - 16);
+    while (need) {
+        const uint32_t b = (uint32_t)__builtin_ctzll(need);
+        need &= need - 1;
+        const uint32_t n_e = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)b);
+        const uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)list_idx, (int)b);
+        const float t = wave_compact_list(p.lists + (uint64_t)li * p.cap, n_e, p.kprime, lane);
+        if (lane == b) { tau = t; cnt = p.kprime; }
+    }
+}
+
+// NTQ query tiles of 16 per wave, KS32 k-steps of 32 dims (dpad = 32 * KS32), WAVES waves per workgroup (4: one per
+// SIMD with the whole register file; 8: two per SIMD, so that one wave's selection and list pushes run beside the
+// other's MFMAs).  Queries per workgroup = 16 * NTQ * WAVES.
+template <int MODE, int NTQ, int KS32, bool CINIT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void flat_scan_bf16x_kernel(ScanParams p) {
+    constexpr int CSLOT = 256 * WAVES;   // per slot: the half tile's accumulator seeds, once per wave
+    constexpr int PIECES = 16 / WAVES;   // fill pieces (4 rows x 256 B) a wave issues per stage
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[BF_NBUF * (BF_STAGE_BYTES + CSLOT)];
+    constexpr int STAGES = KS32 / 4;     // stages (128 dims) per half tile
+    constexpr int UT = 2 * STAGES;       // stages per tile
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t l15 = lane & 15, quad = lane >> 4;
+    constexpr uint32_t QW = 16 * NTQ;    // queries per wave
+    constexpr uint32_t QB = WAVES * QW;
+
+    uint32_t split = 0, q0 = 0, tile_first, tile_mul, cnt_tiles;
+    uint32_t my_query[NTQ];
+    bool q_live[NTQ];
+    float tau[NTQ];
+    uint32_t cnt[NTQ], list_idx[NTQ];
+    float gmax[NTQ][2];
+    if (MODE == MODE_IVF) {
+        const IvfItem it = p.items[blockIdx.x];
+        tile_first = it.tile0;
+        tile_mul = 1;
+        cnt_tiles = it.tile1 - it.tile0;
+        const uint2* iq = p.item_queries + it.qoff;
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) {
+            const uint32_t jq = wave * QW + t * 16 + l15;
+            q_live[t] = jq < it.nq;
+            const uint2 e = q_live[t] ? iq[jq] : make_uint2(0u, 0u);
+            my_query[t] = e.x;
+            list_idx[t] = (e.y + it.list_add) * 4 + quad;  // every quad owns a list
+        }
+    } else {
+        uint32_t q_tile;
+        if (p.xcd_map) {
+            const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+            split = xcd + 8 * (j / p.q_tiles);
+            q_tile = j % p.q_tiles;
+        } else {
+            split = blockIdx.x / p.q_tiles;
+            q_tile = blockIdx.x % p.q_tiles;
+        }
+        q0 = q_tile * QB + wave * QW;
+        const uint32_t own = split < p.n_tiles ? (p.n_tiles - split + p.n_splits - 1) / p.n_splits : 0u;
+        uint32_t jb = 0, jstep = 1;
+        if (MODE == MODE_PRE) {
+            jstep = max(p.pre_stride, 1u);
+            cnt_tiles = min(p.pre_tiles, (own + jstep - 1) / jstep);
+        } else {
+            jb = min(p.tile_off, own);
+            cnt_tiles = min(p.tile_len, own - jb);
+        }
+        tile_mul = jstep * p.n_splits;
+        tile_first = split + jb * p.n_splits;
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) {
+            my_query[t] = q0 + t * 16 + l15;
+            q_live[t] = my_query[t] < p.n_queries;
+            list_idx[t] = (my_query[t] * p.n_splits + split) * 4 + quad;
+        }
+    }
+    const uint32_t t0 = 0, t1 = cnt_tiles;
+#pragma unroll
+    for (int t = 0; t < NTQ; ++t) {
+        tau[t] = -INFINITY;
+        if (MODE != MODE_PRE && p.tau0 && q_live[t]) tau[t] = p.tau0[my_query[t]];
+        if ((p.debug & 1u) || !q_live[t]) tau[t] = INFINITY;
+        cnt[t] = (MODE == MODE_FLAT && p.resume) ? p.list_counts[list_idx[t]] : 0u;
+        gmax[t][0] = gmax[t][1] = -INFINITY;
+    }
+
+#ifdef BF_STAMP
+    const uint64_t st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (t1 > t0) {  // block-uniform
+        // stationary query fragments, pinned in the accumulation half of the register file
+        bf16x8 bq[NTQ][KS32];
+        const uint16_t* __restrict__ gB = (const uint16_t*)p.query_op;
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) {
+            const uint16_t* qrow = gB + (uint64_t)my_query[t] * p.dpad + 8 * quad;
+#pragma unroll
+            for (int ks = 0; ks < KS32; ++ks) bq[t][ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(qrow + ks * 32));
+        }
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t)
+#pragma unroll
+            for (int ks = 0; ks < KS32; ++ks) asm volatile("" : "+a"(bq[t][ks]));
+
+        const unsigned char* __restrict__ gA = (const unsigned char*)p.base_op;
+        const uint32_t row_bytes = p.dpad * 2;
+        uint32_t src_off[PIECES];
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const uint32_t r = (wave * PIECES + i) * 4 + (lane >> 4), cphys = lane & 15;
+            src_off[i] = r * row_bytes + ((cphys ^ (r & 15u)) << 4);
+        }
+        auto issue_piece = [&](uint32_t jj, int u, uint32_t slot, int i) {
+            const uint32_t tile = tile_first + jj * tile_mul;
+            const uint32_t half = (uint32_t)(u / STAGES), s2 = (uint32_t)(u % STAGES);
+            const unsigned char* src = gA + (uint64_t)(tile * TILE_ROWS + half * BF_ROWS) * row_bytes + s2 * 256u;
+            unsigned char* dst = smem + slot * BF_STAGE_BYTES + wave * (PIECES * 1024u);
+            __builtin_amdgcn_global_load_lds((glb_void*)(src + src_off[i]), (lds_void*)(dst + i * 1024), 16, 0, 0);
+            if (CINIT && s2 == 0 && i == PIECES - 1)
+                __builtin_amdgcn_global_load_lds((glb_void*)(p.cinit + (uint64_t)tile * TILE_ROWS + half * BF_ROWS + lane),
+                                                 (lds_void*)(smem + BF_NBUF * BF_STAGE_BYTES + slot * CSLOT + wave * 256u), 4,
+                                                 0, 0);
+        };
+        auto issue_stage = [&](uint32_t tile, int u, uint32_t slot) {
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) issue_piece(tile, u, slot, i);
+        };
+
+        // this lane's fragment of k-step 0 of row tile 0 in slot 0: row l15, physical chunk quad ^ l15; k-step kk of the
+        // stage at that address ^ (kk << 6), row tile mt at + mt * 4096
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+        const uint32_t frag0 = lds0 + l15 * 256u + (((quad ^ l15) & 15u) << 4);
+        bf16x8 a[2][4];  // two fragment sets: the reads of k-step kk + 1 are issued before the MFMAs of k-step kk
+        auto read_frags = [&](bf16x8 (&dst)[4], uint32_t slot_, int kk_) {
+            const uint32_t addr = (frag0 + slot_ * BF_STAGE_BYTES) ^ ((uint32_t)kk_ << 6);
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:4096\n\tds_read_b128 %2, %4 offset:8192\n\t"
+                         "ds_read_b128 %3, %4 offset:12288"
+                         : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3])
+                         : "v"(addr)
+                         : "memory");
+        };
+
+#pragma unroll
+        for (int j = 0; j < BF_PD; ++j) issue_stage(min(t0 + (uint32_t)(j / UT), t1 - 1), j % UT, (uint32_t)j);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_inflight_behind<STAGES, CINIT, PIECES>(0)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(a[0], 0, 0);
+
+        f32x4 acc[4][NTQ];
+        uint32_t slot = 0;
+        const bool lag = BF_STAGGER && WAVES == 8 && wave >= 4;  // wave-uniform
+        for (uint32_t jj = t0; jj < t1; ++jj) {
+            const uint32_t tile = tile_first + jj * tile_mul;
+            static_for<2>([&](auto half_c) {
+                constexpr int half = decltype(half_c)::value;
+                static_for<STAGES>([&](auto s_c) {
+                    constexpr int s = decltype(s_c)::value;
+                    constexpr int u = half * STAGES + s;
+                    if (s == 0) {
+                        if (CINIT) {
+                            const float* cs = (const float*)(smem + BF_NBUF * BF_STAGE_BYTES + slot * CSLOT + wave * 256u);
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt) {
+                                const f32x4 v = *(const f32x4*)(cs + 16 * mt + 4 * quad);
+#pragma unroll
+                                for (int t = 0; t < NTQ; ++t) acc[mt][t] = v;
+                            }
+                        } else {
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                                for (int t = 0; t < NTQ; ++t) acc[mt][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        }
+                    }
+                    static_for<4>([&](auto kk_c) {
+                        constexpr int kk = decltype(kk_c)::value;
+                        constexpr int g = s * 4 + kk;  // k-step within the dimension
+                        // Once per stage: the NEXT stage has landed for this wave; behind the barrier for everybody, and
+                        // everybody has left the previous stage, whose slot takes the stage BF_PD ahead (half of the wave's
+                        // pieces per k-step).  Waves 0-3 do this at k-step 2 of the stage, waves 4-7 at k-step 0: the
+                        // barrier then holds the second wave of every SIMD half a stage behind the first, so that one's
+                        // selection phase runs beside the other's MFMAs instead of both stalling together.
+                        if ((kk < 2) == lag) {
+                            if (kk == 0 || kk == 2) {
+                                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_steady_inflight<STAGES, CINIT, PIECES>(u)) : "memory");
+                                __builtin_amdgcn_s_barrier();
+                            }
+#pragma unroll
+                            for (int i = 0; i < PIECES / 2; ++i)
+                                issue_piece(min(jj + (uint32_t)((u + BF_PD) / UT), t1 - 1), (u + BF_PD) % UT,
+                                            (slot + BF_PD) % BF_NBUF, (PIECES / 2) * (kk & 1) + i);
+                        }
+                        if (kk + 1 < 4) read_frags(a[(kk + 1) % 2], slot, kk + 1);
+                        else read_frags(a[(kk + 1) % 2], (slot + 1) % BF_NBUF, 0);  // next stage (junk behind the last)
+                        asm volatile("s_waitcnt lgkmcnt(4)"
+                                     : "+v"(a[kk % 2][0]), "+v"(a[kk % 2][1]), "+v"(a[kk % 2][2]), "+v"(a[kk % 2][3])
+                                     :
+                                     : "memory");
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                            for (int t = 0; t < NTQ; ++t)
+                                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk % 2][mt], bq[t][g], acc[mt][t], 0, 0, 0);
+                    });
+                    slot = (slot + 1) % BF_NBUF;
+                });
+                // selection behind the half tile
+                const uint32_t row0 = tile * TILE_ROWS + half * BF_ROWS;
+                if (MODE == MODE_PRE) {
+                    const bool plain = !p.valid && !p.filter && (tile + 1) * TILE_ROWS <= p.n;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int t = 0; t < NTQ; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                bool ok = true;
+                                if (!plain) ok = row_live<MODE_FLAT>(p, row0 + 16 * mt + 4 * quad + r);
+                                if (ok) gmax[t][half] = fmaxf(gmax[t][half], acc[mt][t][r]);
+                            }
+                } else if (MODE == MODE_DENSE) {
+#pragma unroll
+                    for (int t = 0; t < NTQ; ++t) {
+                        float* dst = p.dense_scores + (uint64_t)my_query[t] * p.dense_ld + row0 + 4 * quad;
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) *(f32x4*)(dst + 16 * mt) = acc[mt][t];
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NTQ; ++t) {
+                        const f32x4 col[4] = {acc[0][t], acc[1][t], acc[2][t], acc[3][t]};
+                        push_lane16<MODE>(col, row0, quad, lane, p, list_idx[t], tau[t], cnt[t]);
+                    }
+                }
+            });
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#ifdef BF_STAMP
+    if (MODE == MODE_FLAT && tid == 0 && p.tile_off != 0 && p.tile_off + p.tile_len >= p.tiles_per_split) {
+        const uint64_t st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+        uint64_t* out = (uint64_t*)p.pre_max + (uint64_t)blockIdx.x * 2;
+        out[0] = st_c1 - st_c0;
+        out[1] = st_r1 - st_r0;
+    }
+#endif
+
+    if (MODE == MODE_DENSE) return;
+    if (MODE == MODE_PRE) {
+        // 8 group maxima per (query, slice): (quad, half), 16 rows of every sampled tile each
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) {
+            float* dst = p.pre_max + (uint64_t)(q0 + t * 16 + l15) * (8 * p.n_splits) + (split * 4 + quad) * 2;
+            dst[0] = gmax[t][0];
+            dst[1] = gmax[t][1];
+        }
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < NTQ; ++t) {
+        uint64_t need = __builtin_amdgcn_ballot_w64(cnt[t] > p.kprime);
+        while (need) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(need);
+            need &= need - 1;
+            const uint32_t n_e = (uint32_t)__builtin_amdgcn_readlane((int)cnt[t], (int)b);
+            const uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)list_idx[t], (int)b);
+            wave_compact_list(p.lists + (uint64_t)li * p.cap, n_e, p.kprime, lane);
+            if (lane == b) cnt[t] = p.kprime;
+        }
+        if (MODE != MODE_IVF || q_live[t]) p.list_counts[list_idx[t]] = cnt[t];
+    }
+}
+
+#ifndef BF_MF16
+#define BF_MF16 1  // 1: the 16x16x32 form (four candidate lists per query and slice); 0: the 32x32x16 form (two)
+#endif
+#ifndef BF_WAVES8
+#define BF_WAVES8 1  // 1: dimensions up to 384 run eight waves of 32 queries per workgroup; 0: four waves of 64
+#endif
+uint32_t flat_scan_bf16_lists_per_slice() { return BF_MF16 ? 4 : 2; }
+constexpr int BF_NTQ = BF_WAVES8 ? 2 : 4, BF_NW = BF_WAVES8 ? 8 : 4;
+
 // dpad (dims padded to a supported k-step count) and queries per workgroup for a dimension; 0 = unsupported
 uint32_t flat_scan_bf16_dpad(uint32_t dim) {
     const uint32_t ks = (dim + 15) / 16;
@@ -426,7 +748,20 @@ uint32_t flat_scan_bf16_queries_per_block(uint32_t dpad) { return dpad <= 384 ? 
 
 template <int MODE, bool CINIT>
 static hipError_t launch_bf16_mode(const ScanParams& p, hipStream_t stream) {
-    const dim3 grid(p.n_splits * p.q_tiles), block(256);
+    const dim3 grid(p.n_splits * p.q_tiles);
+    dim3 block(256);
+#if BF_MF16
+    if (p.dpad <= 384) block = dim3(64 * BF_NW);
+    switch (p.dpad) {
+    case 128: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE, BF_NTQ, 4, CINIT, BF_NW>), grid, block, 0, stream, p); break;
+    case 256: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE, BF_NTQ, 8, CINIT, BF_NW>), grid, block, 0, stream, p); break;
+    case 384: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE, BF_NTQ, 12, CINIT, BF_NW>), grid, block, 0, stream, p); break;
+    case 512: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE, 2, 16, CINIT, 4>), grid, block, 0, stream, p); break;
+    case 768: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE, 2, 24, CINIT, 4>), grid, block, 0, stream, p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+#endif
     switch (p.dpad) {
     case 128: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE, 2, 8, CINIT>), grid, block, 0, stream, p); break;
     case 256: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE, 2, 16, CINIT>), grid, block, 0, stream, p); break;
@@ -442,7 +777,20 @@ static hipError_t launch_bf16_mode(const ScanParams& p, hipStream_t stream) {
 hipError_t launch_ivf_scan_bf16(const ScanParams& p, uint32_t n_items, hipStream_t stream) {
     if (n_items == 0) return hipSuccess;
     if (!p.cinit) return hipErrorInvalidValue;
-    const dim3 grid(n_items), block(256);
+    const dim3 grid(n_items);
+    dim3 block(256);
+#if BF_MF16
+    if (p.dpad <= 384) block = dim3(64 * BF_NW);
+    switch (p.dpad) {
+    case 128: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_IVF, BF_NTQ, 4, true, BF_NW>), grid, block, 0, stream, p); break;
+    case 256: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_IVF, BF_NTQ, 8, true, BF_NW>), grid, block, 0, stream, p); break;
+    case 384: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_IVF, BF_NTQ, 12, true, BF_NW>), grid, block, 0, stream, p); break;
+    case 512: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_IVF, 2, 16, true, 4>), grid, block, 0, stream, p); break;
+    case 768: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_IVF, 2, 24, true, 4>), grid, block, 0, stream, p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+#endif
     switch (p.dpad) {
     case 128: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE_IVF, 2, 8, true>), grid, block, 0, stream, p); break;
     case 256: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE_IVF, 2, 16, true>), grid, block, 0, stream, p); break;
@@ -456,7 +804,20 @@ hipError_t launch_ivf_scan_bf16(const ScanParams& p, uint32_t n_items, hipStream
 
 template <bool CINIT>
 static hipError_t launch_bf16_dense(const ScanParams& p, hipStream_t stream) {
-    const dim3 grid(p.n_splits * p.q_tiles), block(256);
+    const dim3 grid(p.n_splits * p.q_tiles);
+    dim3 block(256);
+#if BF_MF16
+    if (p.dpad <= 384) block = dim3(64 * BF_NW);
+    switch (p.dpad) {
+    case 128: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_DENSE, BF_NTQ, 4, CINIT, BF_NW>), grid, block, 0, stream, p); break;
+    case 256: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_DENSE, BF_NTQ, 8, CINIT, BF_NW>), grid, block, 0, stream, p); break;
+    case 384: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_DENSE, BF_NTQ, 12, CINIT, BF_NW>), grid, block, 0, stream, p); break;
+    case 512: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_DENSE, 2, 16, CINIT, 4>), grid, block, 0, stream, p); break;
+    case 768: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_DENSE, 2, 24, CINIT, 4>), grid, block, 0, stream, p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+#endif
     switch (p.dpad) {
     case 128: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE_DENSE, 2, 8, CINIT>), grid, block, 0, stream, p); break;
     case 256: hipLaunchKernelGGL((flat_scan_bf16_kernel<MODE_DENSE, 2, 16, CINIT>), grid, block, 0, stream, p); break;

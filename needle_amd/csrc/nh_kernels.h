@@ -51,10 +51,11 @@ uint32_t flat_scan_queries_per_block(int precision, uint32_t dpad);
 // query-stationary kernel holds in registers (then the fp32 scan serves the search).
 uint32_t flat_scan_bf16_dpad(uint32_t dim);
 uint32_t flat_scan_bf16_queries_per_block(uint32_t dpad);
-// Candidate lists are per (query, slice, lane half): 2 * n_splits lists per query.
+// Candidate lists are per (query, slice, lane group): flat_scan_bf16_lists_per_slice() * n_splits lists per query.
+uint32_t flat_scan_bf16_lists_per_slice();
 hipError_t launch_flat_scan_bf16(const ScanParams& p, bool prepass, hipStream_t stream);
-// inverted-list scan: items hold up to flat_scan_bf16_queries_per_block(dpad) entries; entry .y names a PAIR of
-// candidate lists (2 * y and 2 * y + 1, one per lane half)
+// inverted-list scan: items hold up to flat_scan_bf16_queries_per_block(dpad) entries; entry .y names a GROUP of
+// flat_scan_bf16_lists_per_slice() consecutive candidate lists (one per lane group)
 hipError_t launch_ivf_scan_bf16(const ScanParams& p, uint32_t n_items, hipStream_t stream);
 
 // ---- prep.hip --------------------------------------------------------------

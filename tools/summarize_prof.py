@@ -43,7 +43,10 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
 import json
 
 traffic = {}
-for kern, tag in (("flat_scan_bf16_kernel<0", "flat_scan_bf16"), ("flat_scan_f32_kernel<0", "flat_scan_f32")):
+for kern, tag in (("flat_scan_bf16x_kernel<0", "flat_scan_bf16"), ("flat_scan_bf16_kernel<0", "flat_scan_bf16"),
+                  ("flat_scan_f32_kernel<0", "flat_scan_f32")):
+    if tag in traffic:
+        continue
     fetch = write = 0.0
     n_f = n_w = 0
     for sub, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
