@@ -129,7 +129,8 @@ const char* needle_hip_last_error(void);
 int needle_hip_version(void);
 
 /* When on, the first-pass kernel and the whole search are bracketed by HIP
- * events on the library's stream (adds a stream sync per search). */
+ * events on the library's stream (adds a stream sync per search); the events
+ * belong to the context, so searches of all its indexes then run one at a time. */
 needle_hip_status needle_hip_set_profiling(needle_hip_ctx* ctx, int on);
 needle_hip_status needle_hip_get_metrics(needle_hip_ctx* ctx, needle_hip_metrics* out);
 needle_hip_status needle_hip_reset_metrics(needle_hip_ctx* ctx);

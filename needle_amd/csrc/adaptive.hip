@@ -122,8 +122,13 @@ extern "C" needle_hip_status needle_hip_adaptive_search(needle_hip_index* full, 
         if (!std::isfinite(queries[i]))
             return fail(NEEDLE_HIP_ERR_INVALID_VECTOR, "Invalid vector: Vector contains %s at index %u (query %u)",
                         std::isnan(queries[i]) ? "NaN" : "Inf", (unsigned)(i % query_dim), (unsigned)(i / query_dim));
-    if (k == 0 || full->n == 0) {
+    if (k == 0 || full->n == 0) {  // no hits: counts zero, every output row padded as the ABI promises
         memset(out_counts, 0, sizeof(uint32_t) * q);
+        for (uint64_t i = 0; i < (uint64_t)q * k; ++i) {
+            out_ids[i] = UINT64_MAX;
+            out_dists[i] = INFINITY;
+            out_coarse_dists[i] = INFINITY;
+        }
         return NEEDLE_HIP_OK;
     }
     const uint64_t want = (uint64_t)k * std::max<uint32_t>(overfetch, 1);  // quantization.rs:903

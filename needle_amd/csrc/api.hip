@@ -177,12 +177,17 @@ void nh::index_free(needle_hip_index* ix) {
 static bool metric_has_first_pass(int metric) { return metric <= NEEDLE_METRIC_DOT_PRODUCT; }
 
 needle_hip_status nh::upload_mask(needle_hip_index* ix, const uint32_t* mask_host) {
-    if (ix->d_valid) { (void)hipFree(ix->d_valid); ix->d_valid = nullptr; }
-    if (!mask_host || ix->n == 0) return NEEDLE_HIP_OK;
-    const size_t words = (ix->n + 31) / 32;
-    HIP_TRY(hipMalloc((void**)&ix->d_valid, words * sizeof(uint32_t)));
-    HIP_TRY(hipMemcpyAsync(ix->d_valid, mask_host, words * sizeof(uint32_t), hipMemcpyHostToDevice, ix->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ix->ctx->stream));
+    // the new mask is uploaded in full before it replaces the old one: a failure leaves the index as it was
+    uint32_t* fresh = nullptr;
+    if (mask_host && ix->n > 0) {
+        const size_t words = (ix->n + 31) / 32;
+        HIP_TRY(hipMalloc((void**)&fresh, words * sizeof(uint32_t)));
+        hipError_t e = hipMemcpyAsync(fresh, mask_host, words * sizeof(uint32_t), hipMemcpyHostToDevice, ix->ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ix->ctx->stream);
+        if (e != hipSuccess) { (void)hipFree(fresh); HIP_TRY(e); }
+    }
+    if (ix->d_valid) (void)hipFree(ix->d_valid);
+    ix->d_valid = fresh;
     return NEEDLE_HIP_OK;
 }
 
@@ -224,16 +229,23 @@ needle_hip_status nh::finish_operands(needle_hip_index* ix, bool validate) {
         e = hipMalloc((void**)&ix->d_cinit, (size_t)ix->n_pad * sizeof(float));
         if (e == hipSuccess) e = hipMemsetAsync(ix->d_cinit, 0, (size_t)ix->n_pad * sizeof(float), c->stream);
     }
-    if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, 2 * sizeof(uint32_t), c->stream);
+    uint32_t bits[2] = {0u, 0x7f7fffffu};  // running maximum norm, running minimum of the non-zero norms
+    if (e == hipSuccess) e = hipMemcpyAsync(d_flag, bits, sizeof(bits), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess)
         e = launch_row_prep(ix->d_raw, rows, ix->dim, ix->dpad_f32, normalize, ix->op_f32_alias ? nullptr : ix->d_op_f32,
                             nullptr, ix->d_cinit, ix->d_norms, nullptr, d_flag, nullptr, nullptr, c->stream);
-    uint32_t bits = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&bits, d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(bits, d_flag, sizeof(bits), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d_flag);
     HIP_TRY(e);
-    memcpy(&ix->max_norm, &bits, sizeof(float));
+    memcpy(&ix->max_norm, &bits[0], sizeof(float));
+    float min_norm;
+    memcpy(&min_norm, &bits[1], sizeof(float));
+    // Cosine: the first pass scores rows by their true cosine (normalised in double), but the reference's f32
+    // dot(b, b) underflows for rows below about 1e-19 and overflows above about 1e19, which moves its distance by
+    // tens of percent or forces it to 1.0.  No bound on the first-pass score covers that, so an index holding such
+    // a row serves every query from the exact scan.
+    ix->cos_norm_unsafe = ix->metric == NEEDLE_METRIC_COSINE && (min_norm < 1e-15f || ix->max_norm > 1e15f);
     return NEEDLE_HIP_OK;
 }
 
@@ -297,6 +309,8 @@ extern "C" needle_hip_status needle_hip_flat_build_half(needle_hip_ctx* c, const
     if (half_kind != NEEDLE_HALF_F16 && half_kind != NEEDLE_HALF_BF16)
         return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "unknown half precision kind %d", half_kind);
     if (n > 0 && !rows) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "rows is null");
+    if (dim == 0) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "dimension must be positive");
+    if (n >= 0xfffffff0ull - TILE_ROWS) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "at most 2^32-272 rows per index");
     HIP_TRY(hipSetDevice(c->device));
     // upload the 16-bit rows (half the bytes of an f32 base), widen them on the device, then the usual build
     uint16_t* d_half = nullptr;
@@ -528,7 +542,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     // bf16: an index whose earlier batches left many queries undecided keeps more candidates per query (see below)
     if (precision == NEEDLE_PRECISION_BF16) kprime = std::min<uint32_t>(round_up(kprime + ix->bf16_extra_slack, 16), KPRIME_MAX);
     const bool exact_only = precision == NEEDLE_PRECISION_EXACT_SCAN || (!sq8 && !metric_has_first_pass(ix->metric)) ||
-                            kprime > KPRIME_MAX;
+                            kprime > KPRIME_MAX || ix->cos_norm_unsafe;
     if (exact_only) {
         ST_TRY(run_exact(ix, d_queries, nullptr, q, k, d_filter, d_out_ids, d_out_dists, d_out_counts));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -652,11 +666,24 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     sp.resume = 0;
     // Long slices are scanned in three launches of growing length: the thresholds of each are refreshed from
     // everything listed before it, so that the rows listed per query stay near kseed * ln(rows / sample).
-    uint32_t stages[3] = {plan.tiles_per_split, 0, 0};
+    constexpr int MAX_STAGES = 5;
+    uint32_t stages[MAX_STAGES] = {plan.tiles_per_split, 0, 0, 0, 0};
     if (bf16 && seeded && plan.tiles_per_split >= 96 && !(sp.debug & 4u)) {
         stages[0] = std::max<uint32_t>(3 * pre_tiles, plan.tiles_per_split / 10);
         stages[1] = plan.tiles_per_split / 4;
         stages[2] = plan.tiles_per_split - stages[0] - stages[1];
+        if (const char* e = getenv("NEEDLE_HIP_DEBUG_STAGES")) {  // development: percentages of a slice per launch, the last takes the rest
+            unsigned pc[4] = {0, 0, 0, 0};
+            const int got = sscanf(e, "%u,%u,%u,%u", &pc[0], &pc[1], &pc[2], &pc[3]);
+            uint32_t used = 0;
+            int r = 0;
+            for (; r < got && r < MAX_STAGES - 1; ++r) {
+                stages[r] = std::min<uint32_t>(std::max<uint32_t>(1, plan.tiles_per_split * pc[r] / 100), plan.tiles_per_split - used - 1);
+                used += stages[r];
+            }
+            stages[r++] = plan.tiles_per_split - used;
+            for (; r < MAX_STAGES; ++r) stages[r] = 0;
+        }
     }
     if (dense) {
         sp.dense_scores = ix->w_scores.as<float>();
@@ -664,7 +691,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
         HIP_TRY(launch_dense_scores_bf16(sp, c->stream));
         stages[0] = 0;
     }
-    for (int r = 0; r < 3 && stages[r] > 0; ++r) {
+    for (int r = 0; r < MAX_STAGES && stages[r] > 0; ++r) {
         if (r > 0) {
             HIP_TRY(launch_tau_refresh(sp, n_lists, ix->w_tau0.as<float>(), band, c->stream));
             sp.resume = 1;
@@ -826,6 +853,9 @@ static needle_hip_status search_device_locked(needle_hip_index* ix, const float*
         return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "unknown precision %d", precision);
     if (q == 0) return NEEDLE_HIP_OK;
     HIP_TRY(hipSetDevice(c->device));
+    // the timing events belong to the context: with profiling on, searches of ALL its indexes run one at a time
+    std::unique_lock<std::mutex> profiled(c->prof_mu, std::defer_lock);
+    if (c->profiling) profiled.lock();
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     if (k == 0 || ix->n == 0) {
         // clamp_k == 0 -> vec![Vec::new(); queries.len()], src/collection/batch.rs:40-43

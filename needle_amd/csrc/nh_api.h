@@ -62,6 +62,7 @@ struct needle_hip_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     needle_hip_metrics m{};
     std::mutex mu;
+    std::mutex prof_mu;  // held by a whole search while profiling is on (the events ev[] are shared by the context's indexes)
     nh::DevBuf scratch[4];  // operator-level calls
     void* topk_static = nullptr;   // device address of the static top-k workspace on this context's device (ops.hip)
     size_t topk_static_bytes = 0;
@@ -85,6 +86,7 @@ struct needle_hip_index {
     float* d_norms = nullptr;      // [n_pad]
     uint32_t* d_valid = nullptr;   // live-row bitmask (by row id) or null
     float max_norm = 0.0f;
+    bool cos_norm_unsafe = false;  // cosine index holding a row whose norm the reference's f32 arithmetic cannot represent
     uint32_t bf16_extra_slack = 0; // candidates kept per query beyond the default bf16 slack (grows when batches leave queries undecided)
     float bf16_err = 0.0f;         // max over rows of |row operand - its bf16 copy| (set with d_op_bf16); SQ8: max |code vector|
     std::mutex mu;

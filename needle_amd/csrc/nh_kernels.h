@@ -61,8 +61,8 @@ hipError_t launch_ivf_scan_bf16(const ScanParams& p, uint32_t n_items, hipStream
 // ---- prep.hip --------------------------------------------------------------
 // Per row: |b|, |b|^2 (wave-parallel sums; used by the first pass and its error
 // bound only), the operand copies of the first pass (unit-normalised when
-// `normalize`), the accumulator seed -|b|^2/2 when `want_cinit`, and the running
-// maximum norm (as float bits, rows are non-negative).
+// `normalize`), the accumulator seed -|b|^2/2 when `want_cinit`, and in d_max_norm_bits (two words, as float
+// bits, norms are non-negative) the running maximum norm [0] and the running minimum of the non-zero norms [1].
 hipError_t launch_row_prep(const float* d_rows, uint64_t n, uint32_t dim, uint32_t dpad,
                            bool normalize, float* d_op_f32, uint16_t* d_op_bf16, float* d_cinit,
                            float* d_norms, double* d_norm2, uint32_t* d_max_norm_bits,

@@ -55,9 +55,11 @@ __global__ __launch_bounds__(256) void row_prep_kernel(const float* __restrict__
         if (norm2) norm2[row] = s;
         if (cinit) cinit[row] = -(float)(0.5 * s);
         if (max_norm_bits) {
-            // round up so the stored maximum is never below a true norm
+            // round up so the stored maximum is never below a true norm; word [1] keeps the smallest non-zero norm
+            // (the caller starts it at the bits of FLT_MAX)
             const float up = __uint_as_float(__float_as_uint(norm) + 1u);
             atomicMax(max_norm_bits, __float_as_uint(up));
+            if (s > 0.0) atomicMin(max_norm_bits + 1, __float_as_uint(norm));
         }
     }
 }

@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B timing of library variants on the headline workload: tools/ab.sh name[:ENV=VAL,...] ...
+# A/B timing of library variants on the headline workload: tools/ab.sh name[:ENV=VAL+ENV=VAL...] ...
 # (name "main" = needle_amd/lib/libneedle_hip.so, otherwise needle_amd/lib/variants/libneedle_hip_<name>.so)
 for spec in "$@"; do
   name=${spec%%:*}; envs=""
-  [ "$spec" != "$name" ] && envs=$(echo "${spec#*:}" | tr ',' ' ')
+  [ "$spec" != "$name" ] && envs=$(echo "${spec#*:}" | tr '+' ' ')
   lib=$PWD/needle_amd/lib/libneedle_hip.so
   [ "$name" != main ] && lib=$PWD/needle_amd/lib/variants/libneedle_hip_$name.so
   out=$(env $envs NEEDLE_HIP_LIBRARY=$lib timeout -k 10 120 python bench.py --paths none --cpu-seconds 0 --secondary-steps 0 --steps 10 $AB_ARGS 2>/dev/null) || { echo "$spec FAILED"; exit 1; }
