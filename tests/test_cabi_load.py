@@ -33,7 +33,7 @@ def _struct_fields(text, opener, c_style):
 
 def test_metrics_struct_mirrors_agree():
     """needle_hip_get_metrics writes the whole struct: a mirror that is shorter, or ordered differently, reads
-    garbage or is overrun.  The ctypes binding and the Rust block a maintainer copies must match the header."""
+    garbage or is overrun.  The ctypes binding and the Rust crate's mirror must match the header."""
     import ctypes as C
 
     from needle_amd import _lib
@@ -43,7 +43,8 @@ def test_metrics_struct_mirrors_agree():
     binding = [(n, "u64" if t is C.c_uint64 else "f64" if t is C.c_double else str(t)) for n, t in _lib.Metrics._fields_]
     assert binding == header
     assert C.sizeof(_lib.Metrics) == 8 * len(header)
-    rust = _struct_fields(open(os.path.join(ROOT, "INTEGRATION.md")).read(), "pub struct needle_hip_metrics", False)
+    rust = _struct_fields(open(os.path.join(ROOT, "bindings", "rust", "needle-hip-sys", "src", "lib.rs")).read(),
+                          "pub struct needle_hip_metrics", False)
     assert rust == header
 
 
@@ -60,7 +61,8 @@ def test_search_params_mirrors_agree():
                    r"([a-z_0-9]+)\s*;")
     assert header == ["k", "nprobe", "precision", "reserved", "filter_bitmask"]
     assert [n for n, _ in _lib.SearchParams._fields_] == header
-    rust = names(open(os.path.join(ROOT, "INTEGRATION.md")).read(), "pub struct needle_search_params", r"pub\s+([a-z_0-9]+)\s*:")
+    rust = names(open(os.path.join(ROOT, "bindings", "rust", "needle-hip-sys", "src", "lib.rs")).read(),
+                 "pub struct needle_search_params", r"pub\s+([a-z_0-9]+)\s*:")
     assert rust == header
 
 
