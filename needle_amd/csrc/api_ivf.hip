@@ -648,7 +648,9 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     band.berr = ix->bf16_err;
     band.dim = ix->dim; band.metric = ix->metric; band.precision = scan_precision;
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    {
+    const bool no_seed = getenv("NEEDLE_HIP_DEBUG_IVF_NOSEED") != nullptr;  // development: thresholds start at -inf
+    if (no_seed) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ix->w_tau0.p, 0xff800000u, q, c->stream));
+    if (!no_seed) {
         uint32_t sample_rows = IVF_SEED_ROWS;  // fewer rows: weaker thresholds, lists that overflow and are cut back often (measured: 2x the scan time at 128)
         if (const char* e = getenv("NEEDLE_HIP_DEBUG_IVF_SEED_ROWS")) sample_rows = std::min<uint32_t>((uint32_t)atoi(e), IVF_SEED_ROWS);
         if (bf16)

@@ -158,63 +158,146 @@ hipError_t launch_merge_select(const PostParams& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------
-// dense_select: one wave per query over a row of the dense score matrix.
+// dense_select: one wave per query over a row of the dense score matrix: the kprime best live rows by (score, lower
+// id); tau* = the kprime-th score, -inf when every live row is a candidate.
+// The scores are narrowed before the exact selection: every lane keeps the T = ceil(kprime / 64) largest of its own
+// scores; the kprime-th largest of those 64 T values (the pivot) is a score at least kprime rows reach, so the rows at
+// or above it contain the answer and are usually few more than kprime.  They are compacted and the exact bit-by-bit
+// selection runs over them instead of over the whole row (a row of equal scores, or anything else that leaves more
+// than DS_SURV rows above the pivot, takes the selection over the whole row).
 // ---------------------------------------------------------------------------
+constexpr uint32_t DS_SURV = 1024;  // survivors the narrowed selection holds
+constexpr int DS_T = (KPRIME_MAX + 63) / 64;
+
+// kprime-th largest of ord[0 .. total) bit by bit (total >= kprime); zeros sort below every live score
+__device__ inline uint32_t wave_kth_largest_u32(const uint32_t* ord, uint32_t total, uint32_t kprime, uint32_t lane) {
+    uint32_t kth = 0;
+    const uint32_t t4 = (total + 3u) / 4u;  // the caller pads the array with zeros up to a multiple of 256 entries
+    const uint4* o4 = reinterpret_cast<const uint4*>(ord);
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t trial = kth | (1u << bit);
+        uint32_t cnt = 0;
+        for (uint32_t i = lane; i < t4; i += 64) {
+            const uint4 v = o4[i];
+            cnt += (v.x >= trial ? 1u : 0u) + (v.y >= trial ? 1u : 0u) + (v.z >= trial ? 1u : 0u) + (v.w >= trial ? 1u : 0u);
+        }
+#pragma unroll
+        for (int off = 32; off; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
+        if (cnt >= kprime) kth = trial;
+    }
+    return kth;
+}
+
 __global__ __launch_bounds__(64) void dense_select_kernel(PostParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t ord[];  // [round_up(n, 256)], the tail holds 0
+    __shared__ __attribute__((aligned(16))) uint32_t s_ord[DS_SURV];
+    __shared__ uint32_t s_row[DS_SURV];
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
     const uint32_t n4 = (p.n + 255u) & ~255u;
     const float* sc = p.dense_scores + (uint64_t)q * p.dense_ld;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint32_t T = (p.kprime + 63u) / 64u;
     uint32_t live = 0;
+    uint32_t top[DS_T];  // this lane's T largest scores, descending
+#pragma unroll
+    for (int t = 0; t < DS_T; ++t) top[t] = 0u;
     for (uint32_t i = 0; i < p.n; i += 64) {
         const uint32_t r = i + lane;
         bool ok = r < p.n;
         if (ok && p.valid) ok = bit_set(p.valid, r);
         if (ok && p.filter) ok = bit_set(p.filter, r);
-        if (r < p.n) ord[r] = ok ? f2ord(sc[r]) : 0u;  // 0 sorts below every real score (f2ord(-inf) = 0x007fffff)
+        uint32_t o = ok ? f2ord(sc[r]) : 0u;  // 0 sorts below every real score (f2ord(-inf) = 0x007fffff)
+        if (r < p.n) ord[r] = o;
         live += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok));
+#pragma unroll
+        for (int t = 0; t < DS_T; ++t) {  // insertion: o sinks to its place, the smallest falls out
+            const uint32_t hi = max(top[t], o);
+            o = min(top[t], o);
+            top[t] = hi;
+        }
     }
     for (uint32_t r = p.n + lane; r < n4; r += 64) ord[r] = 0u;
     __syncthreads();
-    uint32_t kth = 0, need_ties = 0xffffffffu;
-    float tau = -INFINITY;
-    if (live > p.kprime) {
-        for (int bit = 31; bit >= 0; --bit) {
-            const uint32_t trial = kth | (1u << bit);
-            // per-lane counts over four scores per read (a count does not care which lane sees which score; trial > 0
-            // excludes the tail), one cross-lane sum per bit
-            uint32_t cnt = 0;
-            const uint4* o4 = reinterpret_cast<const uint4*>(ord);
-            for (uint32_t i = 0; i < n4 / 4; i += 64) {
-                const uint4 v = o4[i + lane];
-                cnt += (v.x >= trial ? 1u : 0u) + (v.y >= trial ? 1u : 0u) + (v.z >= trial ? 1u : 0u) + (v.w >= trial ? 1u : 0u);
-            }
-#pragma unroll
-            for (int off = 32; off; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
-            if (cnt >= p.kprime) kth = trial;
-        }
-        uint32_t gt = 0;
+    if (live <= p.kprime) {  // every live row (ord >= 0x007fffff) is a candidate
+        uint32_t base = 0;
         for (uint32_t i = 0; i < p.n; i += 64) {
-            const bool g = (i + lane < p.n) && (ord[i + lane] > kth);
-            gt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(g));
+            const uint32_t r = i + lane;
+            const uint32_t o = r < p.n ? ord[r] : 0u;
+            const bool keep = o >= 1u;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+            if (keep) {
+                const uint64_t slot = (uint64_t)q * p.kprime + base + __builtin_popcountll(m & lt_mask);
+                p.cand_ids[slot] = r;
+                if (p.cand_scores) p.cand_scores[slot] = ord2f(o);
+            }
+            base += __builtin_popcountll(m);
         }
-        need_ties = p.kprime - gt;  // rows scoring exactly the kprime-th score: the lowest ids win
-        tau = ord2f(kth);
-    } else {
-        kth = 1;  // every live row (ord >= 0x007fffff) is a candidate
+        if (lane == 0) { p.cand_n[q] = base; p.tau_star[q] = -INFINITY; }
+        return;
     }
+    // pivot: the kprime-th largest of the lanes' top-T scores (64 T >= kprime of them)
+    uint32_t pivot = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t trial = pivot | (1u << bit);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int t = 0; t < DS_T; ++t)
+            cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64((uint32_t)t < T && top[t] >= trial));
+        if (cnt >= p.kprime) pivot = trial;
+    }
+    // rows at or above the pivot, per lane over its own (strided) rows, then compacted
+    uint32_t mine = 0;
+    for (uint32_t r = lane; r < p.n; r += 64) mine += ord[r] >= pivot ? 1u : 0u;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= (uint32_t)off) incl += t;
+    }
+    const uint32_t surv = (uint32_t)__shfl((int)incl, 63);
+    const uint32_t* sel_ord = ord;  // what the exact selection runs over
+    uint32_t sel_n = p.n;
+    const bool narrowed = pivot > 0u && surv <= DS_SURV;
+    if (narrowed) {
+        uint32_t w = incl - mine;
+        for (uint32_t r = lane; r < p.n; r += 64) {
+            const uint32_t o = ord[r];
+            if (o >= pivot) { s_ord[w] = o; s_row[w] = r; ++w; }
+        }
+        for (uint32_t e = surv + lane; e < ((surv + 255u) & ~255u) && e < DS_SURV; e += 64) s_ord[e] = 0u;
+        __syncthreads();
+        sel_ord = s_ord;
+        sel_n = surv;
+    }
+    const uint32_t kth = wave_kth_largest_u32(sel_ord, sel_n, p.kprime, lane);
+    uint32_t gt = 0;
+    for (uint32_t i = 0; i < sel_n; i += 64) {
+        const bool g = (i + lane < sel_n) && (sel_ord[i + lane] > kth);
+        gt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(g));
+    }
+    const uint32_t need_ties = p.kprime - gt;  // rows scoring exactly the kprime-th score: the lowest ids win
     uint32_t base = 0, ties = 0;
-    for (uint32_t i = 0; i < p.n; i += 64) {
-        const uint32_t r = i + lane;
-        const uint32_t o = r < p.n ? ord[r] : 0u;
-        const bool tie = (live > p.kprime) && o == kth;
+    for (uint32_t i = 0; i < sel_n; i += 64) {
+        const uint32_t e = i + lane;
+        const uint32_t o = e < sel_n ? sel_ord[e] : 0u;
+        const uint32_t row = narrowed ? (e < sel_n ? s_row[e] : 0u) : e;
+        const bool tie = e < sel_n && o == kth;
         const uint64_t tm = __builtin_amdgcn_ballot_w64(tie);
-        const bool keep = (live > p.kprime) ? (o > kth || (tie && ties + __builtin_popcountll(tm & lt_mask) < need_ties)) : (o >= kth);
+        bool keep_tie;
+        if (narrowed) {
+            // survivors are not in row order: a tie's rank is the number of ties with a lower row id
+            uint32_t rank = 0;
+            if (tie)
+                for (uint32_t j = 0; j < sel_n; ++j) rank += (s_ord[j] == kth && s_row[j] < row) ? 1u : 0u;
+            keep_tie = tie && rank < need_ties;
+        } else {
+            keep_tie = tie && ties + __builtin_popcountll(tm & lt_mask) < need_ties;
+        }
+        const bool keep = o > kth || keep_tie;
         const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
         if (keep) {
             const uint64_t slot = (uint64_t)q * p.kprime + base + __builtin_popcountll(m & lt_mask);
-            p.cand_ids[slot] = r;
+            p.cand_ids[slot] = row;
             if (p.cand_scores) p.cand_scores[slot] = ord2f(o);
         }
         base += __builtin_popcountll(m);
@@ -222,7 +305,7 @@ __global__ __launch_bounds__(64) void dense_select_kernel(PostParams p) {
     }
     if (lane == 0) {
         p.cand_n[q] = base;
-        p.tau_star[q] = tau;
+        p.tau_star[q] = ord2f(kth);
     }
 }
 

@@ -14,4 +14,18 @@ for f in glob.glob(sys.argv[1]+'/trace/**/*kernel_stats.csv',recursive=True):
     for r in rows[:14]:
         print(f"{r['Name'][:80]:80s} calls={r['Calls']} total_ms={float(r['TotalDurationNs'])/1e6:.3f} avg_ms={float(r['AverageNs'])/1e6:.3f} pct={r['Percentage']}")
 PY
-grep '"path"' "$OUT/trace.log" | cut -c1-300
+python3 - "$OUT" <<'PY'
+# kernel timeline of the LAST batch (everything after the last gap of more than 2 ms between kernels)
+import csv,glob,sys
+for f in glob.glob(sys.argv[1]+'/trace/**/*kernel_trace.csv',recursive=True):
+    rows=sorted(csv.DictReader(open(f)), key=lambda r:int(r['Start_Timestamp']))
+    start=0
+    for i in range(1,len(rows)):
+        if int(rows[i]['Start_Timestamp'])-int(rows[i-1]['End_Timestamp'])>2_000_000: start=i
+    last=rows[start:]
+    t0=int(last[0]['Start_Timestamp'])
+    print(f"== last batch: {len(last)} kernels, {(int(last[-1]['End_Timestamp'])-t0)/1e6:.3f} ms first start to last end")
+    for r in last:
+        print(f"  +{(int(r['Start_Timestamp'])-t0)/1e6:7.3f} ms  {(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6:7.3f} ms  {r['Kernel_Name'][:100]}")
+PY
+grep '"path"' "$OUT/trace.log" | cut -c1-1500
