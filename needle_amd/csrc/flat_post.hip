@@ -6,6 +6,7 @@
 #include "nh_common.h"
 #include "nh_exact.h"
 #include "nh_kernels.h"
+#include "nh_scan.h"
 #include "nh_select.h"
 
 #include <cstring>
@@ -201,22 +202,35 @@ __global__ __launch_bounds__(64) void dense_select_kernel(PostParams p) {
     uint32_t top[DS_T];  // this lane's T largest scores, descending
 #pragma unroll
     for (int t = 0; t < DS_T; ++t) top[t] = 0u;
-    for (uint32_t i = 0; i < p.n; i += 64) {
-        const uint32_t r = i + lane;
-        bool ok = r < p.n;
-        if (ok && p.valid) ok = bit_set(p.valid, r);
-        if (ok && p.filter) ok = bit_set(p.filter, r);
-        uint32_t o = ok ? f2ord(sc[r]) : 0u;  // 0 sorts below every real score (f2ord(-inf) = 0x007fffff)
-        if (r < p.n) ord[r] = o;
-        live += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok));
+    // four scores per lane and step, several steps in flight (a step per dependent global load would leave the wave
+    // waiting on memory 64 times over)
+    const uint32_t nq4 = (p.n + 3u) & ~3u;  // <= dense_ld: the matrix rows are padded to whole 128-row tiles
+    const bool masked = p.valid != nullptr || p.filter != nullptr;
+#pragma unroll 4
+    for (uint32_t i = lane * 4; i < nq4; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sc + i);
+        uint32_t o4[4];
 #pragma unroll
-        for (int t = 0; t < DS_T; ++t) {  // insertion: o sinks to its place, the smallest falls out
-            const uint32_t hi = max(top[t], o);
-            o = min(top[t], o);
-            top[t] = hi;
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t r = i + j;
+            bool ok = r < p.n;
+            if (masked && ok && p.valid) ok = bit_set(p.valid, r);
+            if (masked && ok && p.filter) ok = bit_set(p.filter, r);
+            o4[j] = ok ? f2ord(v[j]) : 0u;  // 0 sorts below every real score (f2ord(-inf) = 0x007fffff)
+            live += ok ? 1u : 0u;
+            uint32_t o = o4[j];
+#pragma unroll
+            for (int t = 0; t < DS_T; ++t) {  // insertion: o sinks to its place, the smallest falls out
+                const uint32_t hi = max(top[t], o);
+                o = min(top[t], o);
+                top[t] = hi;
+            }
         }
+        *reinterpret_cast<uint4*>(ord + i) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
     }
-    for (uint32_t r = p.n + lane; r < n4; r += 64) ord[r] = 0u;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) live += (uint32_t)__shfl_xor((int)live, off);
+    for (uint32_t r = nq4 + lane; r < n4; r += 64) ord[r] = 0u;
     __syncthreads();
     if (live <= p.kprime) {  // every live row (ord >= 0x007fffff) is a candidate
         uint32_t base = 0;
