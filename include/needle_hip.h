@@ -18,9 +18,15 @@
  * themselves behind the caller's streams: whatever produces those inputs must
  * have finished (stream or device synchronised) before the call.
  *
- * Threading: searches on one index serialise on an internal lock (one
- * workspace per index); builds / mask updates need exclusive access, like the
- * reference's &mut self methods.
+ * Threading: needle_hip_batch_search[_device] (and the sharded form) are
+ * re-entrant on one index, as Collection::batch_search is called under a read
+ * lock from many threads (src/database/internal.rs:319): every call runs on a
+ * search slot of its own -- the index's resident data, a private workspace and
+ * a private stream -- so concurrent batches overlap on the device; at most 4
+ * slots per index exist, a fifth concurrent call waits.  Builds, mask updates
+ * and destroy need exclusive access, like the reference's &mut self methods.
+ * The remaining per-index calls (ivf_probe, adaptive_search) serialise on an
+ * internal lock.
  */
 #ifndef NEEDLE_HIP_H
 #define NEEDLE_HIP_H

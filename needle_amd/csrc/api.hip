@@ -142,6 +142,9 @@ extern "C" needle_hip_status needle_hip_reset_metrics(needle_hip_ctx* c) {
 // ---------------------------------------------------------------------------
 // flat index build
 // ---------------------------------------------------------------------------
+static bool metric_has_first_pass(int metric) { return metric <= NEEDLE_METRIC_DOT_PRODUCT; }
+static void release_workspace(needle_hip_index* ix);
+
 void nh::index_free(needle_hip_index* ix) {
     if (!ix) return;
     {
@@ -150,6 +153,7 @@ void nh::index_free(needle_hip_index* ix) {
     }
     (void)hipSetDevice(ix->ctx->device);
     (void)hipStreamSynchronize(ix->ctx->stream);
+    free_search_slots(ix);
     if (ix->centroids) nh::index_free(ix->centroids);
     if (ix->d_list_pos) (void)hipFree(ix->d_list_pos);
     if (ix->d_list_len) (void)hipFree(ix->d_list_len);
@@ -159,22 +163,145 @@ void nh::index_free(needle_hip_index* ix) {
     if (ix->d_sq_min) (void)hipFree(ix->d_sq_min);
     if (ix->d_sq_scale) (void)hipFree(ix->d_sq_scale);
     if (ix->d_sq_inv) (void)hipFree(ix->d_sq_inv);
-    ix->w_scores.release();
     if (ix->d_op_f32 && !ix->op_f32_alias) (void)hipFree(ix->d_op_f32);
     if (ix->d_raw) (void)hipFree(ix->d_raw);
     if (ix->d_op_bf16) (void)hipFree(ix->d_op_bf16);
     if (ix->d_cinit) (void)hipFree(ix->d_cinit);
     if (ix->d_norms) (void)hipFree(ix->d_norms);
     if (ix->d_valid) (void)hipFree(ix->d_valid);
+    release_workspace(ix);
+    delete ix;
+}
+
+// ---------------------------------------------------------------------------
+// search slots (re-entrant searches)
+// ---------------------------------------------------------------------------
+static void release_workspace(needle_hip_index* ix) {
+    ix->w_scores.release();
     for (DevBuf* b : {&ix->w_qraw, &ix->w_qop, &ix->w_qn2, &ix->w_lists, &ix->w_lcnt, &ix->w_cand, &ix->w_candn,
                       &ix->w_tau, &ix->w_flagged, &ix->w_flagcnt, &ix->w_filter, &ix->w_premax, &ix->w_tau0, &ix->x_keys, &ix->x_u32,
                       &ix->x_u64, &ix->x_sel, &ix->x_mask, &ix->v_probe_ids, &ix->v_probe_d, &ix->v_probe_n, &ix->v_probe32,
                       &ix->v_items, &ix->v_itemq, &ix->v_lbase, &ix->w_qerr, &ix->r_idx, &ix->r_q, &ix->r_ids, &ix->r_dists, &ix->r_cnt, &ix->v_regroup, &ix->b_work, &ix->w_cinit, &ix->w_cscore})
         b->release();
-    delete ix;
 }
 
-static bool metric_has_first_pass(int metric) { return metric <= NEEDLE_METRIC_DOT_PRODUCT; }
+// The view `v` sees the resident data of `p` (pointers and sizes; nothing is owned) through context `vc`.
+static void sync_view(needle_hip_index* v, const needle_hip_index* p, needle_hip_ctx* vc, bool first) {
+    v->ctx = vc;
+    v->is_view = true;
+    v->kind = p->kind; v->n = p->n; v->dim = p->dim; v->n_pad = p->n_pad; v->metric = p->metric; v->arith = p->arith;
+    v->d_raw = p->d_raw; v->d_op_f32 = p->d_op_f32; v->op_f32_alias = p->op_f32_alias; v->d_op_bf16 = p->d_op_bf16;
+    v->dpad_f32 = p->dpad_f32; v->dpad_bf16 = p->dpad_bf16; v->d_cinit = p->d_cinit; v->d_norms = p->d_norms;
+    v->d_valid = p->d_valid; v->max_norm = p->max_norm; v->cos_norm_unsafe = p->cos_norm_unsafe;
+    v->bf16_extra_slack = p->bf16_extra_slack; v->bf16_err = p->bf16_err;
+    v->nlist = p->nlist; v->d_list_pos = p->d_list_pos; v->d_list_len = p->d_list_len; v->d_pos2id = p->d_pos2id;
+    v->d_codes = p->d_codes; v->d_codebooks = p->d_codebooks; v->pq_m = p->pq_m; v->pq_dsub = p->pq_dsub;
+    v->bin_words = p->bin_words; v->d_sq_min = p->d_sq_min; v->d_sq_scale = p->d_sq_scale; v->d_sq_inv = p->d_sq_inv;
+    v->sq_min_norm = p->sq_min_norm;
+    if (first) {  // host-side list geometry: fixed once the index is built
+        v->list_pos = p->list_pos; v->list_len = p->list_len; v->list_tiles_desc = p->list_tiles_desc;
+    }
+}
+
+static SearchSlot* new_search_slot(const needle_hip_index* parent) {
+    SearchSlot* s = new (std::nothrow) SearchSlot();
+    if (!s) return nullptr;
+    s->ctx.device = parent->ctx->device;
+    s->ctx.n_cu = parent->ctx->n_cu;
+    s->ctx.topk_static = parent->ctx->topk_static;
+    s->ctx.topk_static_bytes = parent->ctx->topk_static_bytes;
+    hipError_t e = hipStreamCreateWithFlags(&s->ctx.stream, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&s->ctx.ev[i]);
+    if (e != hipSuccess) {
+        for (int i = 0; i < 4; ++i) if (s->ctx.ev[i]) (void)hipEventDestroy(s->ctx.ev[i]);
+        if (s->ctx.stream) (void)hipStreamDestroy(s->ctx.stream);
+        delete s;
+        return nullptr;
+    }
+    return s;
+}
+
+void nh::free_search_slots(needle_hip_index* ix) {
+    for (SearchSlot* s : ix->slots) {
+        (void)hipStreamSynchronize(s->ctx.stream);
+        release_workspace(&s->ix);
+        release_workspace(&s->cent);
+        for (auto& b : s->ctx.scratch) b.release();
+        for (int i = 0; i < 4; ++i) if (s->ctx.ev[i]) (void)hipEventDestroy(s->ctx.ev[i]);
+        (void)hipStreamDestroy(s->ctx.stream);
+        delete s;
+    }
+    ix->slots.clear();
+}
+
+static bool search_uses_bf16_copy(const needle_hip_index* ix, const needle_search_params* sp) {
+    if (ix->kind == KIND_BINARY || ix->n == 0 || sp->k == 0) return false;
+    if (ix->kind == KIND_IVF && ix->pq_m) return false;  // built with the index
+    if (sp->precision != NEEDLE_PRECISION_BF16 || flat_scan_bf16_dpad(ix->dim) == 0) return false;
+    if (ix->kind == KIND_FLAT && (!metric_has_first_pass(ix->metric) || ix->cos_norm_unsafe)) return false;
+    return choose_kprime((uint32_t)std::min<uint64_t>(sp->k, ix->n), NEEDLE_PRECISION_BF16) <= (uint32_t)KPRIME_MAX;
+}
+
+nh::SlotLease::SlotLease(needle_hip_index* parent, const needle_search_params* params) : parent_(parent) {
+    if (hipSetDevice(parent->ctx->device) != hipSuccess) { st_ = fail(NEEDLE_HIP_ERR_HIP, "hipSetDevice failed"); return; }
+    bool first = false;
+    {
+        std::unique_lock<std::mutex> lk(parent->pool_mu);
+        for (;;) {
+            for (SearchSlot* s : parent->slots)
+                if (!s->busy) { slot_ = s; break; }
+            if (slot_) break;
+            if (parent->slots.size() < MAX_SEARCH_SLOTS) {
+                slot_ = new_search_slot(parent);
+                if (!slot_) { st_ = fail(NEEDLE_HIP_ERR_OUT_OF_MEMORY, "could not create a search slot (stream / events)"); return; }
+                parent->slots.push_back(slot_);
+                first = true;
+                break;
+            }
+            parent->pool_cv.wait(lk);
+        }
+        slot_->busy = true;
+    }
+    // operand copies a view must not build for itself, then the view of the parent's data
+    std::lock_guard<std::mutex> g(parent->mu);
+    if (st_ == NEEDLE_HIP_OK && search_uses_bf16_copy(parent, params)) st_ = ensure_bf16_copy(parent);
+    if (st_ == NEEDLE_HIP_OK && parent->kind == KIND_IVF && parent->centroids && parent->centroids->n > 0 &&
+        flat_scan_bf16_dpad(parent->dim) != 0)
+        st_ = ensure_bf16_copy(parent->centroids);  // the probe step always scores the centroids in bf16
+    slot_->ctx.profiling = parent->ctx->profiling;
+    slot_->ctx.m = needle_hip_metrics{};
+    sync_view(&slot_->ix, parent, &slot_->ctx, first);
+    if (parent->centroids) {
+        sync_view(&slot_->cent, parent->centroids, &slot_->ctx, first);
+        slot_->ix.centroids = &slot_->cent;
+    }
+}
+
+nh::SlotLease::~SlotLease() {
+    if (!slot_) return;
+    {
+        std::lock_guard<std::mutex> g(parent_->mu);  // what the search learned about the index
+        parent_->bf16_extra_slack = std::max(parent_->bf16_extra_slack, slot_->ix.bf16_extra_slack);
+        if (parent_->centroids) parent_->centroids->bf16_extra_slack = std::max(parent_->centroids->bf16_extra_slack, slot_->cent.bf16_extra_slack);
+    }
+    {
+        needle_hip_ctx* pc = parent_->ctx;
+        const needle_hip_metrics& d = slot_->ctx.m;
+        std::lock_guard<std::mutex> g(pc->mu);
+        pc->m.searches += d.searches; pc->m.queries += d.queries; pc->m.fallback_queries += d.fallback_queries;
+        pc->m.scan_launches += d.scan_launches; pc->m.scan_ms_total += d.scan_ms_total;
+        pc->m.refined_queries += d.refined_queries; pc->m.binary_code_scans += d.binary_code_scans;
+        pc->m.list_scans += d.list_scans; pc->m.list_scan_ms_total += d.list_scan_ms_total;
+        if (d.scan_launches) pc->m.last_scan_ms = d.last_scan_ms;
+        if (d.searches && slot_->ctx.profiling) pc->m.last_search_ms = d.last_search_ms;
+    }
+    {
+        std::lock_guard<std::mutex> lk(parent_->pool_mu);
+        slot_->busy = false;
+    }
+    parent_->pool_cv.notify_one();
+}
+
 
 needle_hip_status nh::upload_mask(needle_hip_index* ix, const uint32_t* mask_host) {
     // the new mask is uploaded in full before it replaces the old one: a failure leaves the index as it was
@@ -907,8 +1034,10 @@ extern "C" needle_hip_status needle_hip_batch_search_device(needle_hip_index* ix
     if (!ix || !params) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (q > 0 && (!d_queries || !d_out_counts || (params->k > 0 && (!d_out_ids || !d_out_dists))))
         return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null query or output pointer");
-    std::lock_guard<std::mutex> g(ix->mu);
-    return search_device_locked(ix, d_queries, q, params, params->filter_bitmask, d_out_ids, d_out_dists, d_out_counts);
+    if (q == 0) return NEEDLE_HIP_OK;
+    SlotLease lease(ix, params);  // re-entrant: concurrent searches of one index run on slots of their own
+    ST_TRY(lease.status());
+    return search_device_locked(lease.view(), d_queries, q, params, params->filter_bitmask, d_out_ids, d_out_dists, d_out_counts);
 }
 
 extern "C" needle_hip_status needle_hip_batch_search(needle_hip_index* ix, const float* queries, uint32_t q,
@@ -930,7 +1059,9 @@ extern "C" needle_hip_status needle_hip_batch_search(needle_hip_index* ix, const
         }
     }
     if (q == 0) return NEEDLE_HIP_OK;
-    std::lock_guard<std::mutex> g(ix->mu);
+    SlotLease lease(ix, params);
+    ST_TRY(lease.status());
+    ix = lease.view();
     needle_hip_ctx* c = ix->ctx;
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t k = params->k;

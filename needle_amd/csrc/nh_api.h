@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -68,6 +69,8 @@ struct needle_hip_ctx {
     size_t topk_static_bytes = 0;
 };
 
+namespace nh { struct SearchSlot; }
+
 enum IndexKind { KIND_FLAT = 0, KIND_IVF = 1, KIND_PQ = 2, KIND_SQ8 = 3, KIND_BINARY = 4 };
 
 struct needle_hip_index {
@@ -118,9 +121,40 @@ struct needle_hip_index {
     nh::DevBuf x_keys, x_u32, x_u64, x_sel, x_mask;
     nh::DevBuf v_probe_ids, v_probe_d, v_probe_n, v_probe32, v_items, v_itemq, v_lbase, v_regroup;
     nh::DevBuf b_work;  // binary scan: query codes, histograms, tie counts, collected keys
+    // Re-entrant searches: every batch search runs on a search slot -- a view of this index (same resident data, its
+    // own workspace buffers) bound to a context of its own (own stream, events, metrics).  Slots are created on demand,
+    // at most nh::MAX_SEARCH_SLOTS per index; a search that finds them all busy waits for one.
+    std::mutex pool_mu;
+    std::condition_variable pool_cv;
+    std::vector<nh::SearchSlot*> slots;
+    bool is_view = false;
 };
 
 namespace nh {
+constexpr size_t MAX_SEARCH_SLOTS = 4;
+struct SearchSlot {
+    needle_hip_ctx ctx;       // device and CU count of the parent context; stream, events and metrics of its own
+    needle_hip_index ix;      // view of the parent index
+    needle_hip_index cent;    // view of the parent's centroid index (IVF)
+    bool busy = false;
+};
+// Takes a free slot of `parent` (creating one, or waiting), refreshes its view of the parent's resident data (building
+// the parent's bf16 operand copy first when the search will use it) and gives it back on destruction, folding the
+// slot's metrics into the parent context.
+class SlotLease {
+public:
+    SlotLease(needle_hip_index* parent, const needle_search_params* params);
+    ~SlotLease();
+    SlotLease(const SlotLease&) = delete;
+    SlotLease& operator=(const SlotLease&) = delete;
+    needle_hip_status status() const { return st_; }
+    needle_hip_index* view() const { return slot_ ? &slot_->ix : nullptr; }
+private:
+    needle_hip_index* parent_;
+    SearchSlot* slot_ = nullptr;
+    needle_hip_status st_ = NEEDLE_HIP_OK;
+};
+void free_search_slots(needle_hip_index* ix);
 // flat search of one batch (api.hip); used by the IVF probe step as well
 needle_hip_status flat_search_batch_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k,
                                            int precision, const uint32_t* d_filter, uint64_t* d_out_ids,
