@@ -686,8 +686,9 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     const uint32_t n_tiles = ix->n_pad / TILE_ROWS;
     const uint32_t cap = list_cap(kprime);
     const uint32_t lists_per_split = bf16 ? flat_scan_bf16_lists_per_slice() : 1;  // bf16: one list per lane group
-    // the merge holds a query's lists in LDS: lists * kprime keys of 8 bytes within 64 KB
-    const uint32_t max_splits = std::max<uint32_t>(1, 8192u / (kprime * lists_per_split));
+    // the merge gathers a query's lists in LDS: its one-shot path takes up to 1024 lists (what they actually hold is a
+    // few hundred entries in all); beyond that it falls back to gathering in groups
+    const uint32_t max_splits = std::max<uint32_t>(1, 1024u / lists_per_split);
     SplitPlan plan = plan_splits(q_tiles, n_tiles, (uint32_t)c->n_cu * (uint32_t)flat_scan_blocks_per_cu(precision), max_splits);
     if (const char* ds = getenv("NEEDLE_HIP_DEBUG_SPLITS")) {  // development override, applied before any sizing
         const uint32_t s = (uint32_t)atoi(ds);

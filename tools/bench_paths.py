@@ -258,6 +258,9 @@ def sq8_case(ctx, dev, n, dim, nq, k, steps, oracle=None):
                  "roofline": roofline("hbm", algo / scan_ms / 1e6, "GB/s", "sq8 scan, " + prec + " operands",
                                       "D bytes per vector, once per query block", scan_ms),
                  "scan_tflops": round(2.0 * nq * n * dim / scan_ms / 1e9, 1),
+                 # what actually binds this scan: the codes are multiplied on the matrix cores (every u8 is exact in bf16)
+                 "roofline_mfma": roofline("mfma", 2.0 * nq * n * dim / scan_ms / 1e9, "TFLOP/s", "flat_scan_" + ("bf16" if prec == "bf16" else "f32"),
+                                           "2*Q*N*D flop per batch", scan_ms),
                  "refined_per_batch": m["refined_queries"] / (steps + 1),
                  "fallback_per_batch": m["fallback_queries"] / (steps + 1)}
         if prec == "bf16":
@@ -298,6 +301,8 @@ def pq_case(ctx, dev, n, dim, m_sub, nq, k, steps, oracle=None, build_timing=Tru
                      "scan_tflops": round(2.0 * nq * n * dim / scan_ms / 1e9, 1),
                      "roofline": roofline("hbm", (-(-nq // 256)) * n * m_sub / scan_ms / 1e6, "GB/s", "pq: bf16 scan of the decoded rows",
                                           "m bytes per vector, once per query block (the route streams 2*D bytes of decoded row instead)", scan_ms),
+                     "roofline_mfma": roofline("mfma", 2.0 * nq * n * dim / scan_ms / 1e9, "TFLOP/s", "flat_scan_bf16 over the decoded rows",
+                                               "2*Q*N*D flop per batch", scan_ms),
                      "host_pointer_qps": host_api_qps(ix._h, queries, k, precision=prec),
                      "fallback_per_batch": mm["fallback_queries"] / (steps + 1)}
         else:
