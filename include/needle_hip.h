@@ -12,6 +12,10 @@
  * COPY the caller's data into device memory (the caller keeps its VectorStore,
  * src/storage.rs:624-629).  Outputs are written into caller-allocated arrays.
  * Handles are opaque and released by the matching *_destroy / shutdown call.
+ * needle_hip_shutdown takes along the indexes still bound to the context.  A
+ * context or index handle that is already dead may be passed to its destroy
+ * call again: the address of a destroyed handle is never reused, so the call
+ * is a no-op.  A communicator is destroyed exactly once, before its context.
  *
  * Streams: every call works on a stream the context owns and returns after its
  * work completed.  Entry points that take DEVICE pointers do not order

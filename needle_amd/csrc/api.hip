@@ -54,8 +54,23 @@ extern "C" int needle_hip_metric_from_str(const char* s) {
 static std::mutex g_reg_mu;
 static std::unordered_set<const void*> g_live_indexes, g_live_contexts;
 
+// Handles are registered by address, so an address must never come back: the host block of a destroyed handle is shrunk
+// to the allocator's minimum and kept for the life of the process instead of being returned.  A stale handle handed to
+// a destroy call again (a garbage-collected wrapper that outlived its context, say) can then never name a newer object.
+template <typename T>
+static T* handle_alloc() {
+    void* m = malloc(sizeof(T));
+    return m ? new (m) T() : nullptr;
+}
+template <typename T>
+static void handle_retire(T* h) {
+    h->~T();
+    void* t = realloc((void*)h, 1);
+    if (t && t != (void*)h) free(t);  // the allocator moved the block (it does not when shrinking): nothing left to hold
+}
+
 needle_hip_index* nh::index_new() {
-    needle_hip_index* ix = new (std::nothrow) needle_hip_index();
+    needle_hip_index* ix = handle_alloc<needle_hip_index>();
     if (ix) {
         std::lock_guard<std::mutex> g(g_reg_mu);
         g_live_indexes.insert(ix);
@@ -82,7 +97,7 @@ extern "C" needle_hip_status needle_hip_init(int device_id, needle_hip_ctx** out
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(NEEDLE_HIP_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device_id,
                     prop.gcnArchName);
-    needle_hip_ctx* c = new (std::nothrow) needle_hip_ctx();
+    needle_hip_ctx* c = handle_alloc<needle_hip_ctx>();
     if (!c) return fail(NEEDLE_HIP_ERR_OUT_OF_MEMORY, "host allocation failed");
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -115,7 +130,7 @@ extern "C" void needle_hip_shutdown(needle_hip_ctx* c) {
     for (int i = 0; i < 4; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    delete c;
+    handle_retire(c);
 }
 
 extern "C" needle_hip_status needle_hip_set_profiling(needle_hip_ctx* c, int on) {
@@ -170,7 +185,7 @@ void nh::index_free(needle_hip_index* ix) {
     if (ix->d_norms) (void)hipFree(ix->d_norms);
     if (ix->d_valid) (void)hipFree(ix->d_valid);
     release_workspace(ix);
-    delete ix;
+    handle_retire(ix);
 }
 
 // ---------------------------------------------------------------------------
@@ -270,6 +285,9 @@ nh::SlotLease::SlotLease(needle_hip_index* parent, const needle_search_params* p
         st_ = ensure_bf16_copy(parent->centroids);  // the probe step always scores the centroids in bf16
     slot_->ctx.profiling = parent->ctx->profiling;
     slot_->ctx.m = needle_hip_metrics{};
+    if (getenv("NEEDLE_HIP_DEBUG_TRACE"))
+        fprintf(stderr, "[needle_hip] index %p: search takes slot %p (%s), stream %p\n", (void*)parent, (void*)slot_,
+                first ? "new" : "reused", (void*)slot_->ctx.stream);
     sync_view(&slot_->ix, parent, &slot_->ctx, first);
     if (parent->centroids) {
         sync_view(&slot_->cent, parent->centroids, &slot_->ctx, first);
@@ -279,6 +297,7 @@ nh::SlotLease::SlotLease(needle_hip_index* parent, const needle_search_params* p
 
 nh::SlotLease::~SlotLease() {
     if (!slot_) return;
+    if (getenv("NEEDLE_HIP_DEBUG_TRACE")) fprintf(stderr, "[needle_hip] index %p: slot %p released\n", (void*)parent_, (void*)slot_);
     {
         std::lock_guard<std::mutex> g(parent_->mu);  // what the search learned about the index
         parent_->bf16_extra_slack = std::max(parent_->bf16_extra_slack, slot_->ix.bf16_extra_slack);
@@ -885,6 +904,11 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
         pp.aux_norm = (float)(ix->sq_min_norm * (1.0 + 1e-6));
         if (bf16) pp.qaux = ix->w_qn2.as<double>() + q_pad;
     }
+    if (getenv("NEEDLE_HIP_DEBUG_TRACE"))
+        fprintf(stderr, "[needle_hip] view %p: q %u kprime %u slices %u x %u tiles, %s, %s; base %p qop %p lists %p counts %p cand %p "
+                "queries %p out %p\n", (void*)ix, q, kprime, plan.n_splits, plan.tiles_per_split, seeded ? "seeded" : "unseeded",
+                bf16 ? "bf16" : "fp32", sp.base_op, sp.query_op, (void*)sp.lists, (void*)sp.list_counts, ix->w_cand.p,
+                (const void*)d_queries, (void*)d_out_ids);
     const bool prune = !(sp.debug & 16u);
     if (prune) {
         HIP_TRY(ix->w_cscore.ensure((size_t)q * kprime * sizeof(float)));

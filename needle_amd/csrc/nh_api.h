@@ -40,14 +40,28 @@ struct DevBuf {
     size_t cap = 0;
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        if (p) {
+            static const bool trace_free = getenv("NEEDLE_HIP_DEBUG_TRACE") != nullptr;
+            if (trace_free) fprintf(stderr, "[needle_hip] buf %p: grows, frees %p\n", (void*)this, p);
+            (void)hipFree(p); p = nullptr; cap = 0;
+        }
         size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) { p = nullptr; return e; }
         cap = want;
+        // development: fresh workspace starts as all-ones, so that a kernel reading what nothing wrote shows up at once
+        static const bool poison = getenv("NEEDLE_HIP_DEBUG_POISON") != nullptr;
+        if (poison) { (void)hipMemset(p, 0xff, want); (void)hipDeviceSynchronize(); }
+        static const bool trace = getenv("NEEDLE_HIP_DEBUG_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[needle_hip] buf %p: %zu bytes at %p\n", (void*)this, want, p);
         return hipSuccess;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() {
+        static const bool trace = getenv("NEEDLE_HIP_DEBUG_TRACE") != nullptr;
+        if (trace && p) fprintf(stderr, "[needle_hip] buf %p: released %p\n", (void*)this, p);
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
     template <typename T> T* as() const { return (T*)p; }
 };
 

@@ -52,6 +52,17 @@ def _wait_for_producer(t) -> None:
         torch.cuda.current_stream(t.device).synchronize()
 
 
+def _destroy_handle(owner, destroy_name: str = "needle_hip_index_destroy") -> None:
+    """Destroys owner._h unless the context it is bound to has been closed: closing a context frees everything bound to
+    it, and a wrapper that outlives its context (garbage collected later) must not hand the dead handle to the library
+    again."""
+    h, ctx = getattr(owner, "_h", None), getattr(owner, "ctx", None)
+    ctx_alive = ctx is not None and getattr(ctx, "_h", None) is not None and bool(ctx._h.value)
+    if h is not None and h.value and ctx_alive and not _lib.shutting_down():
+        getattr(_lib.lib(), destroy_name)(h)
+    owner._h = C.c_void_p()
+
+
 class Context:
     """One HIP device (needle_hip_ctx)."""
 
@@ -201,9 +212,7 @@ class FlatIndex:
         return self
 
     def close(self) -> None:
-        if getattr(self, "_h", None) and self._h.value and not _lib.shutting_down():
-            _lib.lib().needle_hip_index_destroy(self._h)
-        self._h = C.c_void_p()
+        _destroy_handle(self)
 
     def __del__(self):  # pragma: no cover
         try:

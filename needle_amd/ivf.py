@@ -16,7 +16,7 @@ from typing import List, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from .index import PRECISION, Context, _f32, _mask_words
+from .index import PRECISION, Context, _f32, _mask_words, _destroy_handle
 
 
 @dataclasses.dataclass
@@ -139,9 +139,7 @@ class IvfIndex:
 
     # ---- device index ---------------------------------------------------------
     def close(self) -> None:
-        if getattr(self, "_h", None) and self._h.value and not _lib.shutting_down():
-            _lib.lib().needle_hip_index_destroy(self._h)
-        self._h = C.c_void_p()
+        _destroy_handle(self)
 
     def __del__(self):  # pragma: no cover
         try:

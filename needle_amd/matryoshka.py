@@ -99,11 +99,18 @@ class AdaptiveIndex:
         self._coarse: Dict[int, C.c_void_p] = {}
 
     def close(self) -> None:
-        if not _lib.shutting_down():
+        ctx_alive = bool(getattr(self.ctx, "_h", None)) and bool(self.ctx._h.value)
+        if ctx_alive and not _lib.shutting_down():  # a closed context has taken its indexes along
             for h in self._coarse.values():
                 _lib.lib().needle_hip_index_destroy(h)
         self._coarse = {}
         self._full.close()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _prefix(self, dims: int) -> C.c_void_p:
         if dims not in self._coarse:

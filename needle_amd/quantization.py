@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .index import PRECISION, Context, _f32, _mask_words
+from .index import PRECISION, Context, _f32, _mask_words, _destroy_handle
 
 F = np.float32
 
@@ -191,9 +191,7 @@ class _CodeIndex:
         self._h = C.c_void_p()
 
     def close(self) -> None:
-        if getattr(self, "_h", None) and self._h.value and not _lib.shutting_down():
-            _lib.lib().needle_hip_index_destroy(self._h)
-        self._h = C.c_void_p()
+        _destroy_handle(self)
 
     def __del__(self):  # pragma: no cover
         try:

@@ -109,9 +109,9 @@ class Communicator:
     def close(self) -> None:
         from . import _lib
 
-        if getattr(self, "_h", None) and self._h.value and not _lib.shutting_down():
-            _lib.lib().needle_hip_comm_destroy(self._h)
-        self._h = C.c_void_p()
+        from .index import _destroy_handle
+
+        _destroy_handle(self, "needle_hip_comm_destroy")
 
 
 class RcclShardedSearcher:

@@ -100,3 +100,35 @@ def test_concurrent_ivf_and_sq8_searches(ctx, oracle):
     for t in range(5):
         assert _equal(got[t][0], serial[t]) and _equal(got[t][2], serial[t]), t
     sq.close()
+
+
+def test_stale_handles_never_name_a_newer_object(oracle):
+    """A wrapper that outlives its context (garbage collected late, say) hands a dead handle to the destroy call: that
+    must stay a no-op however many indexes were created since -- addresses of destroyed handles are not reused."""
+    import ctypes as C
+
+    import needle_amd as na
+    from needle_amd import _lib
+
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((500, 16)).astype(F)
+    q = rng.standard_normal((4, 16)).astype(F)
+    stale = []
+    for _ in range(8):
+        c = na.Context(0)
+        ix = na.FlatIndex(c, base, na.DistanceFunction.Euclidean)
+        stale.append((C.c_void_p(ix._h.value), C.c_void_p(c._h.value)))
+        c.close()       # takes the index along
+        ix.close()      # wrapper of a closed context: nothing reaches the library
+    c = na.Context(0)
+    live = [na.FlatIndex(c, base, na.DistanceFunction.Euclidean) for _ in range(8)]
+    assert not {ix._h.value for ix in live} & {h.value for h, _ in stale}
+    for h, hc in stale:  # what a late __del__ of an unguarded binding would do
+        _lib.lib().needle_hip_index_destroy(h)
+        _lib.lib().needle_hip_shutdown(hc)
+    want = oracle.flat_batch_search(q, base, 5, oracle.EUCLIDEAN)
+    for ix in live:
+        got = ix.search(q, 5)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+        ix.close()
+    c.close()
