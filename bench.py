@@ -94,6 +94,7 @@ class HipBackend:
         self.na = na
         self.ctx = na.Context(dev_index)
         self.comm = None
+        self.comm_error = None
 
     # ---- data -----------------------------------------------------------------------------------
     def rows(self, n, dim, seed, first_row=0):
@@ -122,15 +123,31 @@ class HipBackend:
 
         if not sharded:
             return hip_local_search(index, precision)
-        if self.transport == "nccl":
-            if self.comm is None:
+        if self.transport == "nccl" and self.comm is None and self.comm_error is None:
+            # the communicator behind the C ABI; every rank must end up on the same exchange, so the outcome is agreed on
+            try:
                 self.comm = Communicator(self.ctx)
+                ok = 1
+            except Exception as e:  # noqa: BLE001
+                self.comm_error, ok = f"{type(e).__name__}: {e}", 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if self.comm is not None:
+                    self.comm.close()
+                    self.comm = None
+                self.comm_error = self.comm_error or "needle_hip_comm_init failed on another rank"
+                print(f"[bench] rank {self.rank}: {self.comm_error}; exchanging through torch.distributed", file=sys.stderr)
+        if self.transport == "nccl" and self.comm is not None:
             return RcclShardedSearcher(index._h, self.comm, row_offset, precision=precision).search
         return ShardedSearcher(hip_local_search(index, precision), hip_merge(self.ctx), row_offset).search
 
     def exchange_label(self):
-        return ("one RCCL all-gather behind the C ABI" if self.transport == "nccl"
-                else f"one {self.transport} all-gather (rehearsal), device merge")
+        if self.transport != "nccl":
+            return f"one {self.transport} all-gather (rehearsal), device merge"
+        if self.comm_error is not None:
+            return "one RCCL all-gather through torch.distributed, device merge (C-ABI communicator unavailable)"
+        return "one RCCL all-gather behind the C ABI"
 
     def profile_begin(self):
         self.ctx.set_profiling(True)

@@ -104,12 +104,14 @@ __global__ __launch_bounds__(256) void ivf_seed_tau_kernel(const float* __restri
         const uint32_t l = probe[(uint64_t)q * np];
         const uint32_t p0 = list_pos[l], len = min(list_len[l], min(sample_rows, IVF_SEED_ROWS));
         const float* qv = queries + (uint64_t)q * dim;
-        // every wave scores 64 of the rows; lane L owns row wave * 64 + L: its liveness and seed term are looked up once,
-        // ahead of the scoring loop, which then holds no dependent loads
-        const uint32_t rbase = wave * 64, rmine = rbase + lane;
+        // every wave scores a quarter of the sample (the steps of the scoring loop are serial: an even split keeps the
+        // loop short however many rows are sampled); lane L owns row wave * per + L: its liveness and seed term are
+        // looked up once, ahead of the scoring loop, which then holds no dependent loads
+        const uint32_t per = (len + 3) / 4;  // <= 64
+        const uint32_t rbase = wave * per, rend = min(len, rbase + per), rmine = rbase + lane;
         bool ok = false;
         float ci = 0.0f, mine = 0.0f;
-        if (rmine < len) {
+        if (rmine < rend) {
             const uint32_t id = pos2id[p0 + rmine];
             ok = id != 0xffffffffu;
             if (ok && valid) ok = nh::bit_set(valid, id);
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256) void ivf_seed_tau_kernel(const float* __restri
                     qreg[ps][t] = e < dim ? qv[e] : 0.0f;  // the stride's padding beyond dim holds zeros or is not read
                 }
         }
-        for (uint32_t r0 = rbase; r0 < min(len, rbase + 64); r0 += SEED_STEP) {
+        for (uint32_t r0 = rbase; r0 < rend; r0 += SEED_STEP) {
             float s[SEED_STEP];
 #pragma unroll
             for (uint32_t j = 0; j < SEED_STEP; ++j) s[j] = 0.0f;
@@ -651,7 +653,10 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     const bool no_seed = getenv("NEEDLE_HIP_DEBUG_IVF_NOSEED") != nullptr;  // development: thresholds start at -inf
     if (no_seed) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ix->w_tau0.p, 0xff800000u, q, c->stream));
     if (!no_seed) {
-        uint32_t sample_rows = IVF_SEED_ROWS;  // fewer rows: weaker thresholds, lists that overflow and are cut back often (measured: 2x the scan time at 128)
+        // rows sampled per query: fewer rows shorten this kernel (its scoring steps are serial) and weaken the thresholds
+        // (more rows listed by the scans); measured on 1.25M x 384, nlist 4096, nprobe 32: 256 rows 2.34 ms per batch,
+        // 128 rows 2.20, 64 rows 2.18, 32 rows 2.25
+        uint32_t sample_rows = 128;
         if (const char* e = getenv("NEEDLE_HIP_DEBUG_IVF_SEED_ROWS")) sample_rows = std::min<uint32_t>((uint32_t)atoi(e), IVF_SEED_ROWS);
         if (bf16)
             hipLaunchKernelGGL(ivf_seed_tau_kernel<uint16_t>, dim3(q), dim3(256), 0, c->stream, d_queries, (const uint16_t*)ix->d_op_bf16,

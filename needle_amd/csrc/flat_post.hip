@@ -689,8 +689,12 @@ hipError_t launch_rescore_finalize(const PostParams& p, hipStream_t stream) {
     // block of dimensions staged at a time: a multiple of 4 (groups of four never straddle blocks), the
     // row blocks of all kprime candidates within 48 KB
     uint32_t dc = (48u * 1024u / 4u) / p.kprime;
-    dc = dc > 129 ? 128 : ((dc - 1) / 4) * 4;
+    dc = dc > 65 ? 64 : ((dc - 1) / 4) * 4;  // 64 at most: smaller workgroup images, more of them per CU (measured best of 32 .. 128)
     if (dc < 4) dc = 4;
+    if (const char* e = getenv("NEEDLE_HIP_DEBUG_RSDC")) {  // development: dimensions staged per block
+        const uint32_t v = (uint32_t)atoi(e) / 4 * 4;
+        if (v >= 4 && v <= dc) dc = v;
+    }
     const size_t lds = ((size_t)dc + (size_t)p.kprime * (dc + 1)) * sizeof(float);
     hipLaunchKernelGGL(rescore_finalize_kernel, dim3(p.q), dim3(RS_THREADS), lds, stream, p, dc);
     return hipGetLastError();

@@ -47,7 +47,8 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #define BF_FILL_SPREAD 1  // 1: one fill piece per k-step from BF_FILL_KK on; 0: all four at BF_FILL_KK
 #endif
 #ifndef BF_STAGGER
-#define BF_STAGGER 0      // 1: eight-wave workgroups hold waves 4-7 half a stage behind waves 0-3 (measured 1-2 % slower)
+#define BF_STAGGER 0      // 1: eight-wave workgroups hold waves 4-7 half a stage behind waves 0-3 (measured 1-2 % slower, and 2-3 %
+                          // slower when the lagging waves also fill half a stage later than the leading ones)
 #endif
 #ifndef BF_READ_AHEAD
 #define BF_READ_AHEAD 2   // fragment reads run this many k-steps ahead of the MFMAs (2 or 3)
@@ -565,6 +566,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void flat_scan_bf16x_kernel(
             src_off[i] = r * row_bytes + ((cphys ^ (r & 15u)) << 4);
         }
         auto issue_piece = [&](uint32_t jj, int u, uint32_t slot, int i) {
+#ifdef BF_DEV_NOFILL  // development, timing only: after the prologue nothing is staged any more
+            if (jj != t0) return;
+#endif
             const uint32_t tile = tile_first + jj * tile_mul;
             const uint32_t half = (uint32_t)(u / STAGES), s2 = (uint32_t)(u % STAGES);
             const unsigned char* src = gA + (uint64_t)(tile * TILE_ROWS + half * BF_ROWS) * row_bytes + s2 * 256u;
@@ -680,11 +684,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void flat_scan_bf16x_kernel(
                         for (int mt = 0; mt < 4; ++mt) *(f32x4*)(dst + 16 * mt) = acc[mt][t];
                     }
                 } else {
+#ifdef BF_DEV_NOSEL  // development, timing only: the accumulators are kept alive, nothing is selected
+#pragma unroll
+                    for (int t = 0; t < NTQ; ++t)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) asm volatile("" ::"v"(acc[mt][t]));
+#else
 #pragma unroll
                     for (int t = 0; t < NTQ; ++t) {
                         const f32x4 col[4] = {acc[0][t], acc[1][t], acc[2][t], acc[3][t]};
                         push_lane16<MODE>(col, row0, quad, lane, p, list_idx[t], tau[t], cnt[t]);
                     }
+#endif
                 }
             });
         }
