@@ -175,6 +175,11 @@ class HipBackend:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def host_pointer_qps(self, index, queries_host, k, precision):
+        import tools.bench_paths as bp
+
+        return bp.host_api_qps(index._h, queries_host, k, precision=precision)
+
     def paths(self, want, oracle):
         import tools.bench_paths as bp
 
@@ -329,6 +334,10 @@ def run(args, be):
         parity = {"queries_checked": int(nq), "rank": 0,
                   "ids_equal": bool(np.array_equal(be.host(ids[:nq]).view(np.uint64), oi)),
                   "dists_bit_equal": bool(np.array_equal(gd.view(np.uint32), od.view(np.uint32)))}
+    host_pointer = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0 and hasattr(be, "host_pointer_qps"):
+        # the same batch through the host-pointer entry point: queries up and results down over PCIe (never `value`)
+        host_pointer = be.host_pointer_qps(index, be.host(queries), args.k, args.precision)
     index.close()
     del base
     if rank == 0 and world == 1 and args.paths not in ("", "none"):
@@ -351,7 +360,7 @@ def run(args, be):
                        "sharding": sharding, "exchange": be.exchange_label() if by_rows else None,
                        "recall_at_10": 1.0 if parity is not None and parity["ids_equal"] else None},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
-            "other_first_pass": secondary,
+            "other_first_pass": secondary, "host_pointer_qps": host_pointer,
             "refined_queries_per_step": m["refined_queries"] / max(args.steps, 1),
             "fallback_queries_per_step": m["fallback_queries"] / max(args.steps, 1),
             "index_build_s": round(t_build, 3),

@@ -44,6 +44,7 @@ pub const NEEDLE_METRIC_CHEBYSHEV: c_int = 6;
 // needle_arith
 pub const NEEDLE_ARITH_DISTANCE_RS: c_int = 0; // src/distance.rs sequential sums: Collection::search / batch_search
 pub const NEEDLE_ARITH_ACCEL_CHUNK4: c_int = 1; // src/experimental/gpu/common.rs groups of four: GpuAccelerator
+pub const NEEDLE_ARITH_SERVICE: c_int = 2; // src/services/compute/gpu_kernels.rs:345-358 (operator-level calls only)
 
 // needle_precision: all three return the same ids and distances; BF16 is the fast first pass
 pub const NEEDLE_PRECISION_FP32: i32 = 0;
@@ -129,6 +130,10 @@ extern "C" {
     pub fn needle_hip_normalize_device(ctx: *mut needle_hip_ctx, arith: c_int, d_vectors: *mut f32, n: u64, dim: u32) -> c_int;
     pub fn needle_hip_batch_top_k(ctx: *mut needle_hip_ctx, scores: *const f32, rows: u32, n: u64, k: u32, out_idx: *mut u64, out_scores: *mut f32, out_counts: *mut u32) -> c_int;
     pub fn needle_hip_batch_top_k_device(ctx: *mut needle_hip_ctx, d_scores: *const f32, rows: u32, n: u64, k: u32, d_out_idx: *mut u64, d_out_scores: *mut f32, d_out_counts: *mut u32) -> c_int;
+    pub fn needle_hip_distance_matrix(ctx: *mut needle_hip_ctx, metric: c_int, arith: c_int, queries: *const f32, q: u32, base: *const f32, n: u64, dim: u32, out: *mut f32) -> c_int;
+    pub fn needle_hip_distance_matrix_device(ctx: *mut needle_hip_ctx, metric: c_int, arith: c_int, d_queries: *const f32, q: u32, d_base: *const f32, n: u64, dim: u32, d_out: *mut f32) -> c_int;
+    pub fn needle_hip_multi_query_search(ctx: *mut needle_hip_ctx, metric: c_int, arith: c_int, queries: *const f32, q: u32, base: *const f32, n: u64, dim: u32, k: u32, out_idx: *mut u64, out_dists: *mut f32, out_counts: *mut u32) -> c_int;
+    pub fn needle_hip_multi_query_search_device(ctx: *mut needle_hip_ctx, metric: c_int, arith: c_int, d_queries: *const f32, q: u32, d_base: *const f32, n: u64, dim: u32, k: u32, d_out_idx: *mut u64, d_out_dists: *mut f32, d_out_counts: *mut u32) -> c_int;
     pub fn needle_hip_comm_unique_id(out_id: *mut u8) -> c_int;
     pub fn needle_hip_comm_init(ctx: *mut needle_hip_ctx, unique_id: *const u8, rank: c_int, world: c_int, out: *mut *mut needle_hip_comm) -> c_int;
     pub fn needle_hip_comm_destroy(comm: *mut needle_hip_comm);

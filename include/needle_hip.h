@@ -75,10 +75,16 @@ typedef enum needle_metric {
  *                 Collection::search / batch_search / compute_ground_truth use
  *   ACCEL_CHUNK4: src/experimental/gpu/common.rs:515-581 groups of four --
  *                 what GpuAccelerator::{batch_*_distance, fused_search} use
- *                 (cosine / euclidean / dot only) */
+ *                 (cosine / euclidean / dot only)
+ *   SERVICE     : src/services/compute/gpu_kernels.rs:345-358, the compute
+ *                 service's kernels -- cosine as one loop over three sums from
+ *                 +0.0 with `denominator < f32::EPSILON -> 1.0`; euclidean and
+ *                 dot product as DISTANCE_RS.  Operator-level calls only
+ *                 (batch_distance, distance_matrix, multi_query_search). */
 typedef enum needle_arith {
     NEEDLE_ARITH_DISTANCE_RS = 0,
-    NEEDLE_ARITH_ACCEL_CHUNK4 = 1
+    NEEDLE_ARITH_ACCEL_CHUNK4 = 1,
+    NEEDLE_ARITH_SERVICE = 2
 } needle_arith;
 
 /* Arithmetic of the candidate-generating first pass.  The returned ids and
@@ -412,6 +418,34 @@ needle_hip_status needle_hip_batch_top_k(needle_hip_ctx* ctx, const float* score
 needle_hip_status needle_hip_batch_top_k_device(needle_hip_ctx* ctx, const float* d_scores, uint32_t rows,
                                                 uint64_t n, uint32_t k, uint64_t* d_out_idx,
                                                 float* d_out_scores, uint32_t* d_out_counts);
+
+/* GpuAccelerator::distance_matrix_{cosine,euclidean}, src/services/compute/
+ * gpu_kernels.rs:223-265: every query against every vector, out[j * n + i] =
+ * distance(query j, vector i) (DistanceMatrixResult::get, :113-115).  Any metric
+ * of the chosen arithmetic (SERVICE for the calls above); the dot product is
+ * reported negated, as the distance it is.  q <= 1 048 560. */
+needle_hip_status needle_hip_distance_matrix(needle_hip_ctx* ctx, needle_metric metric, needle_arith arith,
+                                             const float* queries, uint32_t q, const float* base, uint64_t n,
+                                             uint32_t dim, float* out);
+needle_hip_status needle_hip_distance_matrix_device(needle_hip_ctx* ctx, needle_metric metric, needle_arith arith,
+                                                    const float* d_queries, uint32_t q, const float* d_base,
+                                                    uint64_t n, uint32_t dim, float* d_out);
+
+/* GpuAccelerator::multi_query_search, gpu_kernels.rs:267-300 (per query: all
+ * distances, stable sort, truncate to k -- ties keep the lower index), also
+ * DistanceMatrixResult::top_k (:118-129) and, with ACCEL_CHUNK4, the result of
+ * streaming_multi_query_search, src/experimental/gpu/mod.rs:906-951.  The
+ * distance matrix is formed on the device a block of queries at a time and each
+ * block goes through the batch_top_k selection; nothing returns to the host in
+ * between.  Outputs as needle_hip_batch_search ([q][k], tails padded). */
+needle_hip_status needle_hip_multi_query_search(needle_hip_ctx* ctx, needle_metric metric, needle_arith arith,
+                                                const float* queries, uint32_t q, const float* base, uint64_t n,
+                                                uint32_t dim, uint32_t k, uint64_t* out_idx, float* out_dists,
+                                                uint32_t* out_counts);
+needle_hip_status needle_hip_multi_query_search_device(needle_hip_ctx* ctx, needle_metric metric, needle_arith arith,
+                                                       const float* d_queries, uint32_t q, const float* d_base,
+                                                       uint64_t n, uint32_t dim, uint32_t k, uint64_t* d_out_idx,
+                                                       float* d_out_dists, uint32_t* d_out_counts);
 
 /* ---- row-sharded search over the GPUs of one node --------------------------- */
 

@@ -19,7 +19,7 @@ OK, ERR_DIMENSION_MISMATCH, ERR_INVALID_VECTOR, ERR_INVALID_ARGUMENT, ERR_OUT_OF
 # needle_precision
 PRECISION_FP32, PRECISION_BF16, PRECISION_EXACT_SCAN = range(3)
 # needle_arith
-ARITH_DISTANCE_RS, ARITH_ACCEL_CHUNK4 = range(2)
+ARITH_DISTANCE_RS, ARITH_ACCEL_CHUNK4, ARITH_SERVICE = range(3)
 
 #: every symbol include/needle_hip.h declares
 EXPORTS = (
@@ -36,6 +36,8 @@ EXPORTS = (
     "needle_hip_comm_unique_id", "needle_hip_comm_init", "needle_hip_comm_destroy", "needle_hip_comm_rank",
     "needle_hip_comm_world", "needle_hip_sharded_batch_search_device", "needle_hip_shard_slot_bytes",
     "needle_hip_merge_shard_slots_device",
+    "needle_hip_distance_matrix", "needle_hip_distance_matrix_device", "needle_hip_multi_query_search",
+    "needle_hip_multi_query_search_device",
 )
 
 UNIQUE_ID_BYTES = 128
@@ -179,6 +181,12 @@ def lib() -> C.CDLL:
     L.needle_hip_batch_top_k.argtypes = [vp, vp, u32, u64, u32, vp, vp, vp]
     L.needle_hip_batch_top_k_device.restype = i32
     L.needle_hip_batch_top_k_device.argtypes = [vp, vp, u32, u64, u32, vp, vp, vp]
+    for name in ("needle_hip_distance_matrix", "needle_hip_distance_matrix_device"):
+        getattr(L, name).restype = i32
+        getattr(L, name).argtypes = [vp, i32, i32, vp, u32, vp, u64, u32, vp]
+    for name in ("needle_hip_multi_query_search", "needle_hip_multi_query_search_device"):
+        getattr(L, name).restype = i32
+        getattr(L, name).argtypes = [vp, i32, i32, vp, u32, vp, u64, u32, u32, vp, vp, vp]
     L.needle_hip_batch_top_k_device_noalloc.restype = i32
     L.needle_hip_batch_top_k_device_noalloc.argtypes = [vp, vp, u32, u64, u32, vp, vp, vp]
     L.needle_hip_comm_unique_id.restype = i32

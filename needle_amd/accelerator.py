@@ -93,6 +93,20 @@ class GpuAccelerator:
         oi, od, oc = self.ctx.merge_topk(dists, ids, counts, k)
         return [(int(oi[0, j]), float(od[0, j])) for j in range(int(oc[0]))]
 
+    # -- streaming_multi_query_search, gpu/mod.rs:906-951 ----------------------
+    def streaming_multi_query_search(self, queries, vectors, k: int, distance_type: DistanceType) -> List[List[Hit]]:
+        """Every query's streaming_batch_search result.  The chunked search's merge (concatenate the chunks' lists in
+        chunk order, stable sort by distance, truncate) yields the k nearest by (distance, index) over all vectors, so
+        the whole batch is one pass here: distance rows formed on the device a block of queries at a time, each block
+        through the batch_top_k selection."""
+        nq = len(queries)
+        if nq == 0 or len(vectors) == 0:  # gpu/mod.rs:915-917
+            return [[] for _ in range(nq)]
+        q, b = _f32(queries), _f32(vectors)
+        idx, val, cnt = self.ctx.multi_query_search(DistanceType(distance_type).metric(), q, b, min(k, b.shape[0]),
+                                                    _lib.ARITH_ACCEL_CHUNK4)
+        return [[(int(idx[i, j]), float(val[i, j])) for j in range(int(cnt[i]))] for i in range(nq)]
+
     # -- prefiltered_batch_search, gpu/mod.rs:1033-1080 -----------------------
     def prefiltered_batch_search(self, query, vectors: Sequence[Tuple[int, Sequence[float]]], k: int,
                                  distance_type: DistanceType, filter: Callable[[int], bool]) -> List[Hit]:

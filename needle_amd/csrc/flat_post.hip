@@ -470,9 +470,12 @@ __device__ inline bool bound_check_sq8(float tau, float dk, double qconst, doubl
 // the arithmetic is the scalar sequence of nh_exact.h continued across the blocks.
 struct RefAcc { float a, b, c; };  // running sums: a = dot | squared distance, b = |q|^2, c = |row|^2
 
-enum RefKind { RK_RS_COS, RK_RS_DOT, RK_RS_L2, RK_C4_COS, RK_C4_DOT, RK_C4_L2, RK_L1, RK_HAMMING, RK_CHEB, RK_PQ_TABLE };
+enum RefKind { RK_RS_COS, RK_RS_DOT, RK_RS_L2, RK_C4_COS, RK_C4_DOT, RK_C4_L2, RK_L1, RK_HAMMING, RK_CHEB, RK_PQ_TABLE, RK_SV_COS };
 
 __device__ inline int ref_kind(int metric, int arith) {
+    // the compute service's kernels (src/services/compute/gpu_kernels.rs:345-358): its cosine is one loop over three
+    // accumulators from +0.0 with a denominator test; its euclidean and dot product are distance.rs's sums
+    if (arith == NEEDLE_ARITH_SERVICE && metric == NEEDLE_METRIC_COSINE) return RK_SV_COS;
     if (arith == NEEDLE_ARITH_ACCEL_CHUNK4)
         return metric == NEEDLE_METRIC_COSINE ? RK_C4_COS : (metric == NEEDLE_METRIC_EUCLIDEAN ? RK_C4_L2 : RK_C4_DOT);
     switch (metric) {
@@ -496,7 +499,7 @@ __device__ inline void ref_accumulate(RefAcc& s, const float* qs, const float* b
             const float d = qs[i] - bs[i]; const float pd = d * d; s.b = s.b + pd;
             if ((i0 + i + 1) % dim == 0) { s.a = s.a + s.b; s.b = -0.0f; }
         }
-    } else if (KIND == RK_RS_COS) {  // distance.rs:153-164
+    } else if (KIND == RK_RS_COS || KIND == RK_SV_COS) {  // distance.rs:153-164; gpu_kernels.rs:345-350 (same loop body)
         for (uint32_t i = 0; i < i1 - i0; ++i) {
             const float x = qs[i], y = bs[i];
             const float pxy = x * y; s.a = s.a + pxy;
@@ -558,6 +561,11 @@ __device__ inline void ref_accumulate(RefAcc& s, const float* qs, const float* b
 
 __device__ inline float ref_finish(int kind, const RefAcc& s) {
     switch (kind) {
+    case RK_SV_COS: {  // gpu_kernels.rs:348-349
+        const float den = sqrtf(s.b) * sqrtf(s.c);
+        if (den < 1.1920929e-07f) return 1.0f;
+        return 1.0f - (s.a / den);
+    }
     case RK_RS_COS:
     case RK_C4_COS: {
         const float na = sqrtf(s.b);
@@ -1051,6 +1059,78 @@ hipError_t launch_batch_distance(const float* d_query, const float* d_base, uint
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(batch_distance_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_query,
                        d_base, n, dim, metric, arith, d_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// distance_matrix: every query against every row, each value the metric's distance in the chosen arithmetic
+// (dot product negated), row-major [queries][rows].  A workgroup owns 64 rows x 16 queries; the rows and the queries
+// pass through LDS 32 dimensions at a time (coalesced loads), thread (row, query group) then continues its four
+// sums over the staged block in dimension order, so every value is the scalar sequence of the reference.
+// ---------------------------------------------------------------------------
+constexpr uint32_t DM_ROWS = 64, DM_Q = 16, DM_DC = 32;
+
+__global__ __launch_bounds__(256) void distance_matrix_kernel(const float* __restrict__ queries, uint32_t nq,
+                                                              const float* __restrict__ base, uint64_t n, uint32_t dim,
+                                                              int metric, int arith, float* __restrict__ out) {
+    __shared__ float sb[DM_ROWS][DM_DC + 1];  // odd stride: lane = row walks its row without bank conflicts
+    __shared__ float sq[DM_Q][DM_DC];         // a wave reads one query element at a time: broadcast
+    const uint32_t t = threadIdx.x, r = t & 63, g = t >> 6;
+    const uint64_t row0 = (uint64_t)blockIdx.x * DM_ROWS;
+    const uint32_t q0 = blockIdx.y * DM_Q;
+    const int kind = ref_kind(metric, arith);
+    // Rust's f32 Sum folds from -0.0; the chunked sums, the service's cosine and Chebyshev's fold(0.0, max) start at +0.0
+    const float zero = (kind == RK_SV_COS || kind == RK_CHEB || arith == NEEDLE_ARITH_ACCEL_CHUNK4) ? 0.0f : -0.0f;
+    RefAcc acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[j].a = zero; acc[j].b = zero; acc[j].c = zero; }
+    for (uint32_t c0 = 0; c0 < dim; c0 += DM_DC) {
+        const uint32_t len = min(DM_DC, dim - c0);
+        __syncthreads();
+        for (uint32_t i = t; i < DM_ROWS * DM_DC; i += 256) {
+            const uint32_t rr = i / DM_DC, cc = i % DM_DC;
+            sb[rr][cc] = (row0 + rr < n && cc < len) ? base[(row0 + rr) * dim + c0 + cc] : 0.0f;
+        }
+        for (uint32_t i = t; i < DM_Q * DM_DC; i += 256) {
+            const uint32_t qq = i / DM_DC, cc = i % DM_DC;
+            sq[qq][cc] = (q0 + qq < nq && cc < len) ? queries[(uint64_t)(q0 + qq) * dim + c0 + cc] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* qs = sq[g * 4 + j];
+            switch (kind) {
+            case RK_RS_COS: ref_accumulate<RK_RS_COS>(acc[j], qs, sb[r], c0, c0 + len, dim); break;
+            case RK_SV_COS: ref_accumulate<RK_SV_COS>(acc[j], qs, sb[r], c0, c0 + len, dim); break;
+            case RK_RS_DOT: ref_accumulate<RK_RS_DOT>(acc[j], qs, sb[r], c0, c0 + len, dim); break;
+            case RK_RS_L2: ref_accumulate<RK_RS_L2>(acc[j], qs, sb[r], c0, c0 + len, dim); break;
+            case RK_C4_COS: ref_accumulate<RK_C4_COS>(acc[j], qs, sb[r], c0, c0 + len, dim); break;
+            case RK_C4_DOT: ref_accumulate<RK_C4_DOT>(acc[j], qs, sb[r], c0, c0 + len, dim); break;
+            case RK_C4_L2: ref_accumulate<RK_C4_L2>(acc[j], qs, sb[r], c0, c0 + len, dim); break;
+            case RK_L1: ref_accumulate<RK_L1>(acc[j], qs, sb[r], c0, c0 + len, dim); break;
+            case RK_HAMMING: ref_accumulate<RK_HAMMING>(acc[j], qs, sb[r], c0, c0 + len, dim); break;
+            default: ref_accumulate<RK_CHEB>(acc[j], qs, sb[r], c0, c0 + len, dim); break;
+            }
+        }
+    }
+    if (row0 + r >= n) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t qi = q0 + g * 4 + j;
+        if (qi >= nq) continue;
+        float v = ref_finish(kind, acc[j]);
+        if (kind == RK_RS_DOT || kind == RK_C4_DOT) v = metric == NEEDLE_METRIC_COSINE_NORMALIZED ? 1.0f - v : -v;
+        out[(uint64_t)qi * n + row0 + r] = v;
+    }
+}
+
+hipError_t launch_distance_matrix(const float* d_queries, uint32_t q, const float* d_base, uint64_t n, uint32_t dim, int metric,
+                                  int arith, float* d_out, hipStream_t stream) {
+    if (q == 0 || n == 0) return hipSuccess;
+    const uint64_t gx = (n + DM_ROWS - 1) / DM_ROWS, gy = (q + DM_Q - 1) / DM_Q;
+    if (gx > 0x7fffffffull || gy > 65535ull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(distance_matrix_kernel, dim3((uint32_t)gx, (uint32_t)gy), dim3(256), 0, stream, d_queries, q, d_base, n, dim,
+                       metric, arith, d_out);
     return hipGetLastError();
 }
 

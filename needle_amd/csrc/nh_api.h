@@ -78,7 +78,7 @@ struct needle_hip_ctx {
     needle_hip_metrics m{};
     std::mutex mu;
     std::mutex prof_mu;  // held by a whole search while profiling is on (the events ev[] are shared by the context's indexes)
-    nh::DevBuf scratch[4];  // operator-level calls
+    nh::DevBuf scratch[8];  // operator-level calls
     void* topk_static = nullptr;   // device address of the static top-k workspace on this context's device (ops.hip)
     size_t topk_static_bytes = 0;
 };

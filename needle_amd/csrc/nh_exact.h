@@ -158,8 +158,26 @@ __device__ inline float exact_pq_asym(const float* __restrict__ q, const uint8_t
     return sqrtf(dist);
 }
 
+// ---- src/services/compute/gpu_kernels.rs:345-358 (the compute service's own kernels) ----
+// cosine: one loop, three accumulators from +0.0, denominator below f32::EPSILON -> 1.0; euclidean and dot
+// product are distance.rs's sums (f32::sum from -0.0).
+__device__ inline float exact_service(int metric, const float* __restrict__ q, const float* __restrict__ b, uint32_t dim) {
+    if (metric != NEEDLE_METRIC_COSINE) return exact_rs(metric, q, b, dim);
+    float dot = 0.0f, na = 0.0f, nb = 0.0f;
+    for (uint32_t i = 0; i < dim; ++i) {
+        const float x = q[i], y = b[i];
+        const float p = x * y; dot = dot + p;
+        const float pa = x * x; na = na + pa;
+        const float pb = y * y; nb = nb + pb;
+    }
+    const float den = sqrtf(na) * sqrtf(nb);
+    if (den < 1.1920929e-07f) return 1.0f;
+    return 1.0f - (dot / den);
+}
+
 __device__ inline float exact_distance(int metric, int arith, const float* __restrict__ q,
                                        const float* __restrict__ b, uint32_t dim) {
+    if (arith == NEEDLE_ARITH_SERVICE) return exact_service(metric, q, b, dim);
     return arith == NEEDLE_ARITH_ACCEL_CHUNK4 ? exact_chunk4(metric, q, b, dim)
                                               : exact_rs(metric, q, b, dim);
 }

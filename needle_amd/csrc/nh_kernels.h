@@ -201,6 +201,9 @@ hipError_t launch_ivf_mark_lists(const uint32_t* d_qsel, uint32_t f, const uint3
                                  uint32_t* d_mask, uint32_t words, hipStream_t stream);
 
 // One query against n rows, raw distances (dot product positive).
+// every query against every row, [q][n] distances in the chosen arithmetic (flat_post.hip)
+hipError_t launch_distance_matrix(const float* d_queries, uint32_t q, const float* d_base, uint64_t n, uint32_t dim, int metric,
+                                  int arith, float* d_out, hipStream_t stream);
 hipError_t launch_batch_distance(const float* d_query, const float* d_base, uint64_t n, uint32_t dim,
                                  int metric, int arith, float* d_out, hipStream_t stream);
 

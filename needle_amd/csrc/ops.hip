@@ -397,6 +397,132 @@ extern "C" needle_hip_status needle_hip_batch_top_k(needle_hip_ctx* c, const flo
 }
 
 // ---------------------------------------------------------------------------
+// distance matrix and multi-query search (src/services/compute/gpu_kernels.rs:223-300)
+// ---------------------------------------------------------------------------
+static needle_hip_status matrix_check_args(needle_hip_ctx* c, needle_metric metric, needle_arith arith, uint32_t q, uint64_t n,
+                                           uint32_t dim) {
+    if (!c) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (arith != NEEDLE_ARITH_DISTANCE_RS && arith != NEEDLE_ARITH_ACCEL_CHUNK4 && arith != NEEDLE_ARITH_SERVICE)
+        return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "unknown arithmetic %d", (int)arith);
+    if (metric < NEEDLE_METRIC_COSINE || metric > NEEDLE_METRIC_CHEBYSHEV)
+        return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "unknown metric %d", (int)metric);
+    if (arith != NEEDLE_ARITH_DISTANCE_RS && metric != NEEDLE_METRIC_COSINE && metric != NEEDLE_METRIC_EUCLIDEAN &&
+        metric != NEEDLE_METRIC_DOT_PRODUCT)
+        return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "this arithmetic covers cosine, euclidean and dot product only");
+    if (q > 0 && n > 0 && dim == 0) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "dim is 0");
+    if (q > 65535u * 16u) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "at most 1048560 queries per call");
+    if ((n + 63) / 64 > 0x7fffffffull) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "too many vectors");
+    return NEEDLE_HIP_OK;
+}
+
+extern "C" needle_hip_status needle_hip_distance_matrix_device(needle_hip_ctx* c, needle_metric metric, needle_arith arith,
+                                                               const float* d_queries, uint32_t q, const float* d_base,
+                                                               uint64_t n, uint32_t dim, float* d_out) {
+    ST_TRY(matrix_check_args(c, metric, arith, q, n, dim));
+    if (q == 0 || n == 0) return NEEDLE_HIP_OK;  // an empty matrix
+    if (!d_queries || !d_base || !d_out) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_distance_matrix(d_queries, q, d_base, n, dim, (int)metric, (int)arith, d_out, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NEEDLE_HIP_OK;
+}
+
+extern "C" needle_hip_status needle_hip_distance_matrix(needle_hip_ctx* c, needle_metric metric, needle_arith arith,
+                                                        const float* queries, uint32_t q, const float* base, uint64_t n,
+                                                        uint32_t dim, float* out) {
+    ST_TRY(matrix_check_args(c, metric, arith, q, n, dim));
+    if (q == 0 || n == 0) return NEEDLE_HIP_OK;
+    if (!queries || !base || !out) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    const size_t qf = (size_t)q * dim, bf = (size_t)n * dim, of = (size_t)q * n;
+    float* d = nullptr;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(c->scratch[4].ensure((qf + bf + of) * sizeof(float)));
+        d = c->scratch[4].as<float>();
+        HIP_TRY(hipMemcpyAsync(d, queries, qf * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d + qf, base, bf * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    }
+    ST_TRY(needle_hip_distance_matrix_device(c, metric, arith, d, q, d + qf, n, dim, d + qf + bf));
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipMemcpyAsync(out, d + qf + bf, of * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NEEDLE_HIP_OK;
+}
+
+extern "C" needle_hip_status needle_hip_multi_query_search_device(needle_hip_ctx* c, needle_metric metric, needle_arith arith,
+                                                                  const float* d_queries, uint32_t q, const float* d_base,
+                                                                  uint64_t n, uint32_t dim, uint32_t k, uint64_t* d_out_idx,
+                                                                  float* d_out_dists, uint32_t* d_out_counts) {
+    ST_TRY(matrix_check_args(c, metric, arith, q, n, dim));
+    if (q == 0) return NEEDLE_HIP_OK;
+    if (!d_out_counts || (k > 0 && (!d_out_idx || !d_out_dists)) || (n > 0 && (!d_queries || !d_base)))
+        return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (k > (uint32_t)K_MAX) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "k = %u exceeds %d", k, K_MAX);
+    if (n > 0xffffffffull) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "at most 2^32-1 vectors");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    if (k == 0 || n == 0) {
+        HIP_TRY(launch_fill_empty(d_out_idx, d_out_dists, d_out_counts, q, k, c->stream));
+    } else {
+        // a block of queries at a time: its distance rows stay within 1 GiB (and within the selection's 65535 rows)
+        uint64_t blk = (1ull << 30) / (n * sizeof(float));
+        blk = std::max<uint64_t>(16, std::min<uint64_t>(blk / 16 * 16, 65520));
+        const uint32_t rows_max = (uint32_t)std::min<uint64_t>(blk, q);
+        HIP_TRY(c->scratch[5].ensure((size_t)rows_max * n * sizeof(float)));
+        TopkWork w{};
+        HIP_TRY(c->scratch[3].ensure(topk_work_bytes(rows_max, n, k, &w)));
+        for (uint32_t q0 = 0; q0 < q; q0 += rows_max) {
+            const uint32_t rows = std::min(rows_max, q - q0);
+            HIP_TRY(launch_distance_matrix(d_queries + (size_t)q0 * dim, rows, d_base, n, dim, (int)metric, (int)arith,
+                                           c->scratch[5].as<float>(), c->stream));
+            (void)topk_work_bytes(rows, n, k, &w);
+            HIP_TRY(launch_batch_top_k(w, c->scratch[3].p, c->scratch[5].as<float>(), d_out_idx + (size_t)q0 * k,
+                                       d_out_dists + (size_t)q0 * k, d_out_counts + q0, c->stream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NEEDLE_HIP_OK;
+}
+
+extern "C" needle_hip_status needle_hip_multi_query_search(needle_hip_ctx* c, needle_metric metric, needle_arith arith,
+                                                           const float* queries, uint32_t q, const float* base, uint64_t n,
+                                                           uint32_t dim, uint32_t k, uint64_t* out_idx, float* out_dists,
+                                                           uint32_t* out_counts) {
+    ST_TRY(matrix_check_args(c, metric, arith, q, n, dim));
+    if (q == 0) return NEEDLE_HIP_OK;
+    if (!out_counts || (k > 0 && (!out_idx || !out_dists)) || (n > 0 && (!queries || !base)))
+        return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    const size_t kk = k ? k : 1;
+    const size_t qb = ((size_t)q * dim * sizeof(float) + 15) & ~(size_t)15, bb = ((size_t)n * dim * sizeof(float) + 15) & ~(size_t)15;
+    unsigned char* d = nullptr;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(c->scratch[4].ensure(qb + bb + (size_t)q * kk * 12 + (size_t)q * 4 + 64));
+        d = c->scratch[4].as<unsigned char>();
+        if (n > 0) {
+            HIP_TRY(hipMemcpyAsync(d, queries, (size_t)q * dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d + qb, base, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        }
+    }
+    uint64_t* d_idx = (uint64_t*)(d + qb + bb);
+    float* d_ds = (float*)(d + qb + bb + (size_t)q * kk * 8);
+    uint32_t* d_cnt = (uint32_t*)(d + qb + bb + (size_t)q * kk * 12);
+    ST_TRY(needle_hip_multi_query_search_device(c, metric, arith, (const float*)d, q, (const float*)(d + qb), n, dim, k, d_idx, d_ds,
+                                                d_cnt));
+    std::lock_guard<std::mutex> g(c->mu);
+    if (k > 0) {
+        HIP_TRY(hipMemcpyAsync(out_idx, d_idx, (size_t)q * k * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(out_dists, d_ds, (size_t)q * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(out_counts, d_cnt, (size_t)q * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NEEDLE_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
 // merge_topk, host pointers
 // ---------------------------------------------------------------------------
 extern "C" needle_hip_status needle_hip_merge_topk(needle_hip_ctx* c, const float* dists, const uint64_t* ids,

@@ -158,6 +158,41 @@ class Context:
                                                     oi.ctypes.data, od.ctypes.data, oc.ctypes.data))
         return oi[:, :k], od[:, :k], oc
 
+    def distance_matrix(self, metric: DistanceFunction, queries, base, arith: int = _lib.ARITH_SERVICE) -> np.ndarray:
+        """[queries][vectors] distances (the dot product negated), every value in the chosen arithmetic:
+        distance_matrix_cosine / _euclidean of src/services/compute/gpu_kernels.rs:223-265 with ARITH_SERVICE."""
+        q, b = _f32(queries), _f32(base)
+        if q.ndim != 2 or b.ndim != 2 or (q.shape[0] and b.shape[0] and q.shape[1] != b.shape[1]):
+            raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH, "Dimension mismatch")
+        out = np.empty((q.shape[0], b.shape[0]), dtype=np.float32)
+        if out.size:
+            _lib.check(_lib.lib().needle_hip_distance_matrix(self._h, int(metric), arith, q.ctypes.data, q.shape[0],
+                                                             b.ctypes.data, b.shape[0], q.shape[1], out.ctypes.data))
+        return out
+
+    def distance_matrix_device(self, metric: DistanceFunction, d_queries, d_base, d_out, arith: int = _lib.ARITH_SERVICE) -> None:
+        for t in (d_queries, d_base):
+            _wait_for_producer(t)
+        _lib.check(_lib.lib().needle_hip_distance_matrix_device(self._h, int(metric), arith, d_queries.data_ptr(),
+                                                                int(d_queries.shape[0]), d_base.data_ptr(),
+                                                                int(d_base.shape[0]), int(d_queries.shape[1]), d_out.data_ptr()))
+
+    def multi_query_search(self, metric: DistanceFunction, queries, base, k: int, arith: int = _lib.ARITH_SERVICE):
+        """(idx[q,k] uint64, dists[q,k] f32, counts[q] uint32): per query the k nearest vectors by (distance, index),
+        formed on the device from the distance matrix (multi_query_search, gpu_kernels.rs:267-300)."""
+        q, b = _f32(queries), _f32(base)
+        if q.ndim != 2 or b.ndim != 2 or (q.shape[0] and b.shape[0] and q.shape[1] != b.shape[1]):
+            raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH, "Dimension mismatch")
+        nq, kk = q.shape[0], max(k, 1)
+        idx = np.full((nq, kk), np.iinfo(np.uint64).max, dtype=np.uint64)
+        val = np.full((nq, kk), np.inf, dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        if nq:
+            _lib.check(_lib.lib().needle_hip_multi_query_search(self._h, int(metric), arith, q.ctypes.data, nq,
+                                                                b.ctypes.data if b.size else None, b.shape[0], q.shape[1], k,
+                                                                idx.ctypes.data, val.ctypes.data, cnt.ctypes.data))
+        return idx[:, :k], val[:, :k], cnt
+
     def merge_topk_device(self, d_dists, d_ids, d_counts, lists: int, q: int, per: int, k: int, d_out_ids, d_out_dists,
                           d_out_counts) -> None:
         _lib.check(_lib.lib().needle_hip_merge_topk_device(self._h, d_dists.data_ptr(), d_ids.data_ptr(),

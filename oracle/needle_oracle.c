@@ -437,6 +437,36 @@ NDL_API void ndl_accel_batch_distance(const float *query, const float *base, siz
     if (dtype == 2) for (size_t i = 0; i < n; ++i) out[i] = -out[i];
 }
 
+/* The compute service's distances, src/services/compute/gpu_kernels.rs:345-358.
+ * cosine: ONE loop, three accumulators from +0.0 (`let (mut dot, mut na, mut nb) = (0.0f32, ...)`),
+ * denom = sqrt(na) * sqrt(nb), denom < f32::EPSILON -> 1.0; euclidean: (x-y)*(x-y) summed by
+ * f32::sum (from -0.0), sqrt; dot product: negated sum.  dtype: 0 cosine, 1 euclidean, 2 dot. */
+NDL_API float ndl_service_distance(const float *a, const float *b, size_t n, int dtype) {
+    if (dtype == 0) {
+        float dot = 0.0f, na = 0.0f, nb = 0.0f;
+        for (size_t i = 0; i < n; ++i) {
+            float x = a[i], y = b[i];
+            float p = x * y; dot = dot + p;
+            float pa = x * x; na = na + pa;
+            float pb = y * y; nb = nb + pb;
+        }
+        float denom = sqrtf(na) * sqrtf(nb);
+        if (denom < 1.1920929e-07f) return 1.0f;
+        return 1.0f - (dot / denom);
+    }
+    if (dtype == 1) return ndl_euclidean(a, b, n);
+    return -ndl_dot(a, b, n);
+}
+
+/* distance_matrix_cosine / distance_matrix_euclidean, gpu_kernels.rs:223-265: row-major
+ * [queries][vectors]. */
+NDL_API void ndl_service_distance_matrix(const float *queries, size_t q, const float *base, size_t n,
+                                         size_t dim, int dtype, float *out) {
+    for (size_t j = 0; j < q; ++j)
+        for (size_t i = 0; i < n; ++i)
+            out[j * n + i] = ndl_service_distance(queries + j * dim, base + i * dim, dim, dtype);
+}
+
 /* Top-k of a score vector: the k smallest by (score, index), ascending.
  * Covers batch_top_k (gpu/mod.rs:534-549: stable sort + take k) and
  * partial_sort_top_k (gpu/common.rs:584-626: max-heap of k with strict '<'

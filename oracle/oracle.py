@@ -76,6 +76,10 @@ def _declare(L: C.CDLL) -> None:
     L.ndl_accel_distances.argtypes = [_f32p, _f32p, sz, sz, C.c_int, _f32p]
     L.ndl_accel_batch_distance.restype = None
     L.ndl_accel_batch_distance.argtypes = [_f32p, _f32p, sz, sz, C.c_int, _f32p]
+    L.ndl_service_distance.restype = C.c_float
+    L.ndl_service_distance.argtypes = [_f32p, _f32p, sz, C.c_int]
+    L.ndl_service_distance_matrix.restype = None
+    L.ndl_service_distance_matrix.argtypes = [_f32p, sz, _f32p, sz, sz, C.c_int, _f32p]
     L.ndl_top_k.restype = sz
     L.ndl_top_k.argtypes = [_f32p, sz, sz, _u64p, _f32p]
     L.ndl_accel_fused_search.restype = sz
@@ -294,6 +298,22 @@ def accel_batch_distance(query, base, dtype: int) -> np.ndarray:
     q, b = _f32(query), _f32(base)
     out = np.empty(b.shape[0], dtype=np.float32)
     lib().ndl_accel_batch_distance(_p(q, _f32p), _p(b, _f32p), b.shape[0], q.size, dtype, _p(out, _f32p))
+    return out
+
+
+def service_distance(a, b, dtype: int) -> float:
+    """gpu_kernels.rs:345-358 (the compute service's own cosine / euclidean / dot product)."""
+    x, y = _f32(a), _f32(b)
+    return float(lib().ndl_service_distance(_p(x, _f32p), _p(y, _f32p), x.size, dtype))
+
+
+def service_distance_matrix(queries, base, dtype: int) -> np.ndarray:
+    """distance_matrix_cosine / _euclidean, gpu_kernels.rs:223-265: [queries][vectors]."""
+    q, b = _f32(queries), _f32(base)
+    out = np.empty((q.shape[0], b.shape[0]), dtype=np.float32)
+    if out.size:
+        lib().ndl_service_distance_matrix(_p(q, _f32p), q.shape[0], _p(b, _f32p), b.shape[0], q.shape[1], dtype,
+                                          _p(out, _f32p))
     return out
 
 

@@ -422,3 +422,20 @@ def test_kat_matryoshka_and_adaptive_search(oracle):
     tie = np.array([[0, 0, 1, 0], [0, 0, -1, 0], [0, 0, 1, 0], [3, 0, 0, 0]], dtype=np.float32)
     ids3, full3, _ = oracle.adaptive_search(np.zeros(4, dtype=np.float32), tie, 2, 3, 2)
     assert full3.tolist() == [1.0, 1.0, 1.0] and ids3.tolist() == [2, 1, 0]
+
+
+def test_compute_service_kernels(oracle):
+    """src/services/compute/gpu_kernels.rs:345-358 and the situations of its tests (:407-440)."""
+    q = np.array([[1.0] * 8, [0.0] * 8], dtype=np.float32)
+    v = np.array([[1.0] * 8, [0.5] * 8, [0.0] * 8], dtype=np.float32)
+    m = oracle.service_distance_matrix(q, v, 0)
+    assert m.shape == (2, 3) and m[0, 0] < m[0, 2]
+    assert m[0, 2] == 1.0 and (m[1] == 1.0).all()  # denominator below f32::EPSILON -> 1.0
+    # one loop over three sums from +0.0: differs from distance.rs's cosine only in the zero-norm rule and the sums' start
+    a = np.array([3.0, 4.0], dtype=np.float32)
+    b = np.array([4.0, 3.0], dtype=np.float32)
+    assert oracle.service_distance(a, b, 0) == np.float32(1.0) - np.float32(24.0) / (np.float32(5.0) * np.float32(5.0))
+    assert oracle.service_distance(a, b, 1) == np.sqrt(np.float32(2.0))
+    assert oracle.service_distance(a, b, 2) == -24.0
+    tiny = np.full(4, 1e-4, dtype=np.float32)  # norms 2e-4 each: product 4e-8 < EPSILON, although neither norm is zero
+    assert oracle.service_distance(tiny, tiny, 0) == 1.0 and oracle.cosine(tiny, tiny) != 1.0
