@@ -193,6 +193,20 @@ class HipBackend:
             dist.destroy_process_group()
 
 
+def oracle_build_flags():
+    """The compiler flags the CPU baseline was built with, read from its Makefile."""
+    flags = "unknown"
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "Makefile")) as f:
+            for ln in f:
+                if ln.startswith("CFLAGS"):
+                    flags = ln.split("=", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return f"cc {flags} (no -march=native: the reference's default build targets baseline x86-64)"
+
+
 def load_oracle():
     from oracle import oracle as orc  # checker + CPU baseline only; never on the product path
 
@@ -316,7 +330,7 @@ def run(args, be):
         oi, od, oc = orc.flat_batch_search(hq[threads:threads + nq], hb, args.k, int(metric), threads=threads)
         dt = time.perf_counter() - t1
         cpu_baseline = {"value": round(nq / dt, 3), "unit": "queries/s", "cores": threads, "kind": "port",
-                        "flags": "gcc -O2 -ffp-contract=off (no -march=native: the reference's default build is scalar)",
+                        "flags": oracle_build_flags(),
                         "sample": f"{nq} of the {args.queries} queries against the full {rows_total}x{args.dim} base, "
                                   f"{threads} threads, one query per task (oracle/needle_oracle.c, reference scalar order)"}
         gi = be.host(ids[threads:threads + nq]).view(np.uint64)
