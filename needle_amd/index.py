@@ -7,6 +7,7 @@ already hold their data on the GPU); all compute is inside libneedle_hip.so.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -60,6 +61,11 @@ def _destroy_handle(owner, destroy_name: str = "needle_hip_index_destroy") -> No
     ctx_alive = ctx is not None and getattr(ctx, "_h", None) is not None and bool(ctx._h.value)
     if h is not None and h.value and ctx_alive and not _lib.shutting_down():
         getattr(_lib.lib(), destroy_name)(h)
+    elif h is not None and h.value and not ctx_alive and os.environ.get("NEEDLE_HIP_DEBUG_STALE_LOG"):
+        import threading  # development: record wrappers that outlived their context
+
+        with open(os.environ["NEEDLE_HIP_DEBUG_STALE_LOG"], "a") as f:
+            f.write(f"{type(owner).__name__} handle {h.value:#x} dropped after its context, thread {threading.current_thread().name}\n")
     owner._h = C.c_void_p()
 
 
