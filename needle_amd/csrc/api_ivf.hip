@@ -550,7 +550,7 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     if (dbg_t) HIP_TRY(hipStreamSynchronize(c->stream));
     const double t_probe_done = now();
     const uint32_t max_lists_per_query = std::max<uint32_t>(np, 2048);  // bounds the list bookkeeping, not correctness
-    const uint32_t item_queries = bf16 ? flat_scan_bf16_queries_per_block(flat_scan_bf16_dpad(ix->dim)) : (uint32_t)TILE_QUERIES;
+    const uint32_t item_queries = bf16 ? flat_scan_bf16_ivf_queries_per_block(flat_scan_bf16_dpad(ix->dim)) : (uint32_t)TILE_QUERIES;
     uint32_t run = 8;
     for (; run < (1u << 20); run *= 2) {
         uint64_t worst = 0;

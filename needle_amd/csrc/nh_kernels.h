@@ -51,6 +51,7 @@ uint32_t flat_scan_queries_per_block(int precision, uint32_t dpad);
 // query-stationary kernel holds in registers (then the fp32 scan serves the search).
 uint32_t flat_scan_bf16_dpad(uint32_t dim);
 uint32_t flat_scan_bf16_queries_per_block(uint32_t dpad);
+uint32_t flat_scan_bf16_ivf_queries_per_block(uint32_t dpad);  // query slots of an inverted-list work item
 // Candidate lists are per (query, slice, lane group): flat_scan_bf16_lists_per_slice() * n_splits lists per query.
 uint32_t flat_scan_bf16_lists_per_slice();
 hipError_t launch_flat_scan_bf16(const ScanParams& p, bool prepass, hipStream_t stream);
