@@ -50,6 +50,10 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #define BF_STAGGER 0      // 1: eight-wave workgroups hold waves 4-7 half a stage behind waves 0-3 (measured 1-2 % slower, and 2-3 %
                           // slower when the lagging waves also fill half a stage later than the leading ones)
 #endif
+#ifndef BF_FLAT_SKIP_DEAD
+#define BF_FLAT_SKIP_DEAD 0  // 1: waves of the flat scan whose query slots are all padding skip the matrix work too
+#endif
+#define BF_SKIPS_DEAD(MODE) ((MODE) == MODE_IVF || (BF_FLAT_SKIP_DEAD && (MODE) == MODE_FLAT))
 #ifndef BF_READ_AHEAD
 #define BF_READ_AHEAD 2   // fragment reads run this many k-steps ahead of the MFMAs (2 or 3)
 #endif
@@ -532,6 +536,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void flat_scan_bf16x_kernel(
             q_live[t] = my_query[t] < p.n_queries;
             list_idx[t] = (my_query[t] * p.n_splits + split) * 4 + quad;
         }
+        if (BF_SKIPS_DEAD(MODE)) wave_live = q0 < p.n_queries;  // the padding slots of the last query block
     }
     const uint32_t t0 = 0, t1 = cnt_tiles;
 #pragma unroll
@@ -555,7 +560,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void flat_scan_bf16x_kernel(
             const uint16_t* qrow = gB + (uint64_t)my_query[t] * p.dpad + 8 * quad;
 #pragma unroll
             for (int ks = 0; ks < KS32; ++ks)
-                bq[t][ks] = (MODE != MODE_IVF || wave_live) ? __builtin_bit_cast(bf16x8, *(const uint4*)(qrow + ks * 32)) : bf16x8{};
+                bq[t][ks] = (!BF_SKIPS_DEAD(MODE) || wave_live) ? __builtin_bit_cast(bf16x8, *(const uint4*)(qrow + ks * 32)) : bf16x8{};
         }
 #pragma unroll
         for (int t = 0; t < NTQ; ++t)
@@ -607,10 +612,24 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void flat_scan_bf16x_kernel(
         for (int j = 0; j < BF_PD; ++j) issue_stage(min(t0 + (uint32_t)(j / UT), t1 - 1), j % UT, (uint32_t)j);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_inflight_behind<STAGES, CINIT, PIECES>(0)) : "memory");
         __builtin_amdgcn_s_barrier();
-        if (MODE != MODE_IVF || wave_live) read_frags(a[0], 0, 0);
+        uint32_t slot = 0;
+        if (BF_SKIPS_DEAD(MODE) && !wave_live) {
+            // no live query in this wave: it keeps its share of the staging and meets every barrier, nothing else
+            for (uint32_t jj = t0; jj < t1; ++jj) {
+                static_for<UT>([&](auto u_c) {
+                    constexpr int u = decltype(u_c)::value;
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_steady_inflight<STAGES, CINIT, PIECES>(u)) : "memory");
+                    __builtin_amdgcn_s_barrier();
+#pragma unroll
+                    for (int i = 0; i < PIECES; ++i)
+                        issue_piece(min(jj + (uint32_t)((u + BF_PD) / UT), t1 - 1), (u + BF_PD) % UT, (slot + BF_PD) % BF_NBUF, i);
+                    slot = (slot + 1) % BF_NBUF;
+                });
+            }
+        } else {
+        read_frags(a[0], 0, 0);
 
         f32x4 acc[4][NTQ];
-        uint32_t slot = 0;
         const bool lag = BF_STAGGER && WAVES == 8 && wave >= 4;  // wave-uniform
         for (uint32_t jj = t0; jj < t1; ++jj) {
             const uint32_t tile = tile_first + jj * tile_mul;
@@ -653,19 +672,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void flat_scan_bf16x_kernel(
                                 issue_piece(min(jj + (uint32_t)((u + BF_PD) / UT), t1 - 1), (u + BF_PD) % UT,
                                             (slot + BF_PD) % BF_NBUF, (PIECES / 2) * (kk & 1) + i);
                         }
-                        if (MODE != MODE_IVF || wave_live) {
-                            if (kk + 1 < 4) read_frags(a[(kk + 1) % 2], slot, kk + 1);
-                            else read_frags(a[(kk + 1) % 2], (slot + 1) % BF_NBUF, 0);  // next stage (junk behind the last)
-                            asm volatile("s_waitcnt lgkmcnt(4)"
-                                         : "+v"(a[kk % 2][0]), "+v"(a[kk % 2][1]), "+v"(a[kk % 2][2]), "+v"(a[kk % 2][3])
-                                         :
-                                         : "memory");
+                        if (kk + 1 < 4) read_frags(a[(kk + 1) % 2], slot, kk + 1);
+                        else read_frags(a[(kk + 1) % 2], (slot + 1) % BF_NBUF, 0);  // next stage (junk behind the last)
+                        asm volatile("s_waitcnt lgkmcnt(4)"
+                                     : "+v"(a[kk % 2][0]), "+v"(a[kk % 2][1]), "+v"(a[kk % 2][2]), "+v"(a[kk % 2][3])
+                                     :
+                                     : "memory");
 #pragma unroll
-                            for (int mt = 0; mt < 4; ++mt)
+                        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                                for (int t = 0; t < NTQ; ++t)
-                                    acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk % 2][mt], bq[t][g], acc[mt][t], 0, 0, 0);
-                        }
+                            for (int t = 0; t < NTQ; ++t)
+                                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk % 2][mt], bq[t][g], acc[mt][t], 0, 0, 0);
                     });
                     slot = (slot + 1) % BF_NBUF;
                 });
@@ -690,7 +707,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void flat_scan_bf16x_kernel(
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt) *(f32x4*)(dst + 16 * mt) = acc[mt][t];
                     }
-                } else if (MODE != MODE_IVF || wave_live) {
+                } else {
 #ifdef BF_DEV_NOSEL  // development, timing only: the accumulators are kept alive, nothing is selected
 #pragma unroll
                     for (int t = 0; t < NTQ; ++t)
@@ -706,6 +723,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void flat_scan_bf16x_kernel(
                 }
             });
         }
+        }  // live wave
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 #ifdef BF_STAMP
