@@ -69,6 +69,45 @@ def timed(fn, steps, warmup):
     return (time.perf_counter() - t0) / steps, out
 
 
+def concurrent_qps(handle, dq, k, callers, steps, *, nprobe=0, precision="bf16", d_filter=None):
+    """Aggregate rate of `callers` host threads searching ONE index at the same time (the library runs every call on a
+    search slot of its own: private workspace and stream), each with its own result buffers."""
+    import threading
+
+    nq = dq.shape[0]
+    sp = _lib.SearchParams(k=k, nprobe=nprobe, precision=PRECISION[precision], reserved=0,
+                           filter_bitmask=d_filter.data_ptr() if d_filter is not None else None)
+    bufs = [(torch.empty((nq, k), dtype=torch.int64, device=dq.device), torch.empty((nq, k), dtype=torch.float32, device=dq.device),
+             torch.empty((nq,), dtype=torch.int32, device=dq.device)) for _ in range(callers)]
+    torch.cuda.synchronize()
+    gate = threading.Barrier(callers + 1)
+    errs = []
+
+    def work(t):
+        ids, dists, counts = bufs[t]
+        try:
+            for r in range(steps + 1):
+                if r == 1:
+                    gate.wait()  # one untimed call each (slot creation, workspace), then everybody starts together
+                _lib.check(_lib.lib().needle_hip_batch_search_device(handle, dq.data_ptr(), nq, C.byref(sp), ids.data_ptr(),
+                                                                     dists.data_ptr(), counts.data_ptr()))
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            gate.abort()
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(callers)]
+    for th in ths:
+        th.start()
+    gate.wait()
+    t0 = time.perf_counter()
+    for th in ths:
+        th.join()
+    dt = time.perf_counter() - t0
+    if errs:
+        raise errs[0]
+    return round(callers * steps * nq / dt, 1)
+
+
 COLLECT = None  # a list: entries are appended instead of printed (bench.py folds them into its JSON line)
 
 
@@ -146,6 +185,9 @@ def flat_case(ctx, dev, name, n, dim, nq, k, metric, steps, filt_frac=None, orac
         if prec == precisions[0]:
             extra["host_pointer_qps"] = host_api_qps(ix._h, queries.cpu().numpy(), k, precision=prec,
                                                      filt_words=_mask_words(keep, n) if keep is not None else None)
+            if nq <= 2000:  # small batches leave the chip idle between their short kernels: what concurrent callers gain
+                extra["concurrent_callers_qps"] = {str(t): concurrent_qps(ix._h, queries, k, t, max(steps, 4), precision=prec,
+                                                                          d_filter=d_filter) for t in (2, 4)}
         if oracle is not None:
             s = min(nq, parity_queries)
             oi, od, oc = oracle.flat_batch_search(queries[:s].cpu().numpy(), base.cpu().numpy(), k, int(metric), filt=keep,
@@ -209,7 +251,9 @@ def ivf_case(ctx, dev, n, dim, nlist, nprobe, nq, k, steps, oracle=None, centroi
              "list_scan_only_GBps_bf16_streamed": round(bytes_bf16 / list_scan_ms / 1e6, 1) if list_scan_ms > 0 else None,
              "roofline": roofline("hbm", bytes_items / sec / 1e9, "GB/s", "ivf list-major scan (whole search)",
                                   "4*D bytes per row of every probed list, once per tile of the queries probing it", sec * 1e3),
-             "host_pointer_qps": host_api_qps(h, queries, k, nprobe=nprobe, precision="bf16"), "fp32_list_scan_ms_per_batch": round(sec32 * 1e3, 3), "build_s": round(build_s, 2), "train_s": round(train_s, 2),
+             "host_pointer_qps": host_api_qps(h, queries, k, nprobe=nprobe, precision="bf16"),
+             "concurrent_callers_qps": {str(t): concurrent_qps(h, dq, k, t, max(steps, 4), nprobe=nprobe) for t in (2, 4)},
+             "fp32_list_scan_ms_per_batch": round(sec32 * 1e3, 3), "build_s": round(build_s, 2), "train_s": round(train_s, 2),
              "scanned_pairs": pairs,
              "bytes_listmajor": bytes_items, "bytes_each_probed_list_once": bytes_once, "bytes_unbatched": bytes_unbatched,
              "listmajor_GBps_over_whole_search": round(bytes_items / sec / 1e9, 1),
@@ -265,6 +309,7 @@ def sq8_case(ctx, dev, n, dim, nq, k, steps, oracle=None):
                  "fallback_per_batch": m["fallback_queries"] / (steps + 1)}
         if prec == "bf16":
             extra["host_pointer_qps"] = host_api_qps(ix._h, queries, k, precision=prec)
+            extra["concurrent_callers_qps"] = {str(t): concurrent_qps(ix._h, dq, k, t, max(steps, 4), precision=prec) for t in (2, 4)}
         if oracle is not None:
             s, ns = 8, 400_000
             small = na.quantization.Sq8Index(ctx, sq, codes[:ns])
@@ -304,6 +349,7 @@ def pq_case(ctx, dev, n, dim, m_sub, nq, k, steps, oracle=None, build_timing=Tru
                      "roofline_mfma": roofline("mfma", 2.0 * nq * n * dim / scan_ms / 1e9, "TFLOP/s", "flat_scan_bf16 over the decoded rows",
                                                "2*Q*N*D flop per batch", scan_ms),
                      "host_pointer_qps": host_api_qps(ix._h, queries, k, precision=prec),
+                     "concurrent_callers_qps": {str(t): concurrent_qps(ix._h, dq, k, t, max(steps, 4), precision=prec) for t in (2, 4)},
                      "fallback_per_batch": mm["fallback_queries"] / (steps + 1)}
         else:
             qg = min(3, (150 * 1024) // (m_sub * 1024))
