@@ -61,6 +61,7 @@ def parse(argv=None):
                     help="N > 1: rows (default; row blocks, all-gather + merge) or queries (replicas, no exchange)")
     ap.add_argument("--secondary-steps", type=int, default=2, help="steps of the other first-pass precision (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--ivf-leg-seconds", type=float, default=420.0, help="N > 1: time limit of the row-sharded IVF leg")
     ap.add_argument("--parity-queries", type=int, default=16, help="N > 1: queries rank 0 checks against the oracle (0 = skip)")
     ap.add_argument("--paths", default=DEFAULT_PATHS, help="N = 1: other configurations folded into the line ('none' = skip)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
@@ -179,6 +180,63 @@ class HipBackend:
         import tools.bench_paths as bp
 
         return bp.host_api_qps(index._h, queries_host, k, precision=precision)
+
+    def ivf_sharded(self, base, queries, row_offset, rows_total, k, exact_ids, steps):
+        """The metric's IVF configuration (nlist 4096, nprobe 32) over the same row blocks: every rank builds an inverted
+        index over ITS rows with the SAME centroids (trained by rank 0 on the head of its block, broadcast), so the probe
+        lists agree on every rank and the merged result is the whole index's.  Timed like the flat leg; recall@10 is
+        taken against the exact result of the flat leg."""
+        import ctypes as C
+
+        import tools.bench_paths as bp
+        from needle_amd import _lib
+        from needle_amd.sharded import RcclShardedSearcher, ShardedSearcher, hip_local_search_handle, hip_merge
+
+        nlist, nprobe = 4096, 32
+        n, dim = int(base.shape[0]), int(base.shape[1])
+        cents = torch.zeros((nlist, dim), dtype=torch.float32)
+        train_s = 0.0
+        if self.rank == 0:
+            sample = base[: min(n, 100 * nlist)].cpu().numpy()
+            c, train_s = bp.trained_centroids(self.ctx, sample, nlist, 8)
+            cents = torch.from_numpy(np.ascontiguousarray(c, dtype=np.float32))
+        if self.world > 1:
+            t = cents.to(self.device) if self.transport == "nccl" else cents
+            dist.broadcast(t, src=0)
+            cents = t.cpu()
+        cents_h = np.ascontiguousarray(cents.numpy())
+        hb = base.cpu().numpy()
+        h = C.c_void_p()
+        t0 = time.perf_counter()
+        _lib.check(_lib.lib().needle_hip_ivf_build(self.ctx._h, hb.ctypes.data, n, dim, cents_h.ctypes.data, nlist, None, None,
+                                                   C.byref(h)))
+        build_s = time.perf_counter() - t0
+        del hb
+        try:
+            if self.transport == "nccl" and self.comm is not None:
+                search = RcclShardedSearcher(h, self.comm, row_offset, nprobe=nprobe, precision="bf16").search
+            else:
+                search = ShardedSearcher(hip_local_search_handle(h, nprobe, "bf16"), hip_merge(self.ctx), row_offset).search
+            out = search(queries, k)
+            self.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out = search(queries, k)
+            self.barrier()
+            el = self.max_over_ranks(time.perf_counter() - t0)
+        finally:
+            _lib.lib().needle_hip_index_destroy(h)
+        got, want = out[0].cpu().numpy(), exact_ids.cpu().numpy()
+        hits = sum(len(np.intersect1d(got[i], want[i])) for i in range(got.shape[0]))
+        return {"path": "ivf_sharded",
+                "workload": f"IVF-Flat nlist={nlist} nprobe={nprobe} over {rows_total}x{dim} unit rows in {self.world} row blocks "
+                            f"(same centroids on every rank), k={k}",
+                "queries": int(queries.shape[0]), "ms_per_batch": round(el / steps * 1e3, 3),
+                "qps": round(queries.shape[0] * steps / el, 1), "recall_at_10_vs_exact": round(hits / max(want.size, 1), 4),
+                "recall_note": "of the EXACT top 10; i.i.d. Gaussian rows have no cluster structure, so 32 of 4096 lists hold few of "
+                               "them -- the returned rows are the reference IvfIndex's own (bit-equal in tests/test_config_sizes_gpu.py, "
+                               "tests/test_sharded_indexes_gpu.py)",
+                "exchange": self.exchange_label(), "rows_per_gpu": n, "build_s": round(build_s, 2), "train_s": round(train_s, 2)}
 
     def paths(self, want, oracle):
         import tools.bench_paths as bp
@@ -353,9 +411,12 @@ def run(args, be):
         # the same batch through the host-pointer entry point: queries up and results down over PCIe (never `value`)
         host_pointer = be.host_pointer_qps(index, be.host(queries), args.k, args.precision)
     index.close()
-    del base
-    if rank == 0 and world == 1 and args.paths not in ("", "none"):
-        paths = be.paths(args.paths.split(","), orc)
+    want_paths = [] if args.paths in ("", "none") else args.paths.split(",")
+    sharded_ivf = by_rows and world > 1 and "ivf" in want_paths and hasattr(be, "ivf_sharded")
+    if not sharded_ivf:
+        del base
+    if rank == 0 and world == 1 and want_paths:
+        paths = be.paths(want_paths, orc)
 
     line = None
     if rank == 0:
@@ -380,6 +441,33 @@ def run(args, be):
             "index_build_s": round(t_build, 3),
             "paths": paths,
         }
+    if sharded_ivf:
+        # The flat line above is complete.  The IVF leg is collective: should a rank fail or stall in it, the others
+        # would wait for ever, so a watchdog prints the flat line and ends the process instead of losing the run.
+        import threading
+
+        done = threading.Event()
+
+        def bail():
+            if done.is_set():
+                return
+            if line is not None:
+                line["paths"] = [{"path": "ivf_sharded", "error": f"not finished within {args.ivf_leg_seconds:.0f} s"}]
+                print(json.dumps(line), flush=True)
+            os._exit(0 if line is None or parity_ok(line) else 3)
+
+        dog = threading.Timer(args.ivf_leg_seconds, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            leg = be.ivf_sharded(base, queries, lo, rows_total, args.k, ids, max(2, min(args.steps, 5)))
+        except Exception as e:  # noqa: BLE001
+            leg = {"path": "ivf_sharded", "error": f"{type(e).__name__}: {e}"}
+        done.set()
+        dog.cancel()
+        del base
+        if line is not None:
+            line["paths"] = [leg]
     return line
 
 
