@@ -433,6 +433,9 @@ def run(args, be):
                        "rows_total": rows_total, "rows_per_gpu": hi - lo, "dim": args.dim, "queries": args.queries,
                        "k": args.k, "first_pass": args.precision, "queries_total": total_queries,
                        "sharding": sharding, "exchange": be.exchange_label() if by_rows else None,
+                       "scaling_reference": ("the same 10M-row base on ONE GPU is the `flat10m` entry of the N = 1 line's `paths` "
+                                             "(the N = 1 headline itself is the 1M-row configuration of the metric)")
+                       if by_rows and world > 1 else None,
                        "recall_at_10": 1.0 if parity is not None and parity["ids_equal"] else None},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
             "other_first_pass": secondary, "host_pointer_qps": host_pointer,
