@@ -163,9 +163,11 @@ hipError_t launch_merge_select(const PostParams& p, hipStream_t stream) {
 // id); tau* = the kprime-th score, -inf when every live row is a candidate.
 // The scores are narrowed before the exact selection: every lane keeps the T = ceil(kprime / 64) largest of its own
 // scores; the kprime-th largest of those 64 T values (the pivot) is a score at least kprime rows reach, so the rows at
-// or above it contain the answer and are usually few more than kprime.  They are compacted and the exact bit-by-bit
-// selection runs over them instead of over the whole row (a row of equal scores, or anything else that leaves more
-// than DS_SURV rows above the pivot, takes the selection over the whole row).
+// or above it contain the answer and are usually few more than kprime.  A second sweep over the row (it comes from L2)
+// compacts them into LDS and the exact bit-by-bit selection runs over them.  The row itself is never held in LDS -- a
+// workgroup needs 8 KB, so a CU keeps a wave per query in flight on every slot it has.  A row that leaves more than
+// DS_SURV rows above the pivot (equal scores), or whose live rows sit in too few lanes for a pivot, takes the selection
+// over the whole row, re-read from memory for every bit.
 // ---------------------------------------------------------------------------
 constexpr uint32_t DS_SURV = 1024;  // survivors the narrowed selection holds
 constexpr int DS_T = (KPRIME_MAX + 63) / 64;
@@ -189,12 +191,24 @@ __device__ inline uint32_t wave_kth_largest_u32(const uint32_t* ord, uint32_t to
     return kth;
 }
 
+// order-preserving image of four consecutive scores (rows i .. i+3, i a multiple of 4 below the padded row length);
+// 0 -- below every real score, f2ord(-inf) = 0x007fffff -- for rows that are masked out or beyond n
+__device__ inline void dense_ord4(const PostParams& p, const float* __restrict__ sc, uint32_t i, bool masked, uint32_t (&o4)[4]) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(sc + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t r = i + j;
+        bool ok = r < p.n;
+        if (masked && ok && p.valid) ok = bit_set(p.valid, r);
+        if (masked && ok && p.filter) ok = bit_set(p.filter, r);
+        o4[j] = ok ? f2ord(v[j]) : 0u;
+    }
+}
+
 __global__ __launch_bounds__(64) void dense_select_kernel(PostParams p) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t ord[];  // [round_up(n, 256)], the tail holds 0
     __shared__ __attribute__((aligned(16))) uint32_t s_ord[DS_SURV];
     __shared__ uint32_t s_row[DS_SURV];
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
-    const uint32_t n4 = (p.n + 255u) & ~255u;
     const float* sc = p.dense_scores + (uint64_t)q * p.dense_ld;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const uint32_t T = (p.kprime + 63u) / 64u;
@@ -208,16 +222,11 @@ __global__ __launch_bounds__(64) void dense_select_kernel(PostParams p) {
     const bool masked = p.valid != nullptr || p.filter != nullptr;
 #pragma unroll 4
     for (uint32_t i = lane * 4; i < nq4; i += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(sc + i);
         uint32_t o4[4];
+        dense_ord4(p, sc, i, masked, o4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t r = i + j;
-            bool ok = r < p.n;
-            if (masked && ok && p.valid) ok = bit_set(p.valid, r);
-            if (masked && ok && p.filter) ok = bit_set(p.filter, r);
-            o4[j] = ok ? f2ord(v[j]) : 0u;  // 0 sorts below every real score (f2ord(-inf) = 0x007fffff)
-            live += ok ? 1u : 0u;
+            live += o4[j] != 0u ? 1u : 0u;
             uint32_t o = o4[j];
 #pragma unroll
             for (int t = 0; t < DS_T; ++t) {  // insertion: o sinks to its place, the smallest falls out
@@ -226,108 +235,135 @@ __global__ __launch_bounds__(64) void dense_select_kernel(PostParams p) {
                 top[t] = hi;
             }
         }
-        *reinterpret_cast<uint4*>(ord + i) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
     }
 #pragma unroll
     for (int off = 32; off; off >>= 1) live += (uint32_t)__shfl_xor((int)live, off);
-    for (uint32_t r = nq4 + lane; r < n4; r += 64) ord[r] = 0u;
-    __syncthreads();
-    if (live <= p.kprime) {  // every live row (ord >= 0x007fffff) is a candidate
+    // pivot: the kprime-th largest of the lanes' top-T scores (64 T >= kprime of them); 0 when the live rows sit in
+    // too few lanes, or when every live row is a candidate anyway
+    uint32_t pivot = 0;
+    if (live > p.kprime) {
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t trial = pivot | (1u << bit);
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int t = 0; t < DS_T; ++t)
+                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64((uint32_t)t < T && top[t] >= trial));
+            if (cnt >= p.kprime) pivot = trial;
+        }
+    }
+    // second sweep: the rows at or above the pivot (all live rows when there is none), compacted in sweep order
+    const uint32_t floor_ord = max(pivot, 1u);
+    uint32_t surv = 0;
+    for (uint32_t i0 = 0; i0 < nq4; i0 += 256) {  // every lane takes every step: the ballots below count whole waves
+        const uint32_t i = i0 + lane * 4;
+        uint32_t o4[4] = {0u, 0u, 0u, 0u};
+        if (i < nq4) dense_ord4(p, sc, i, masked, o4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool keep = o4[j] >= floor_ord;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+            const uint32_t pos = surv + __builtin_popcountll(m & lt_mask);
+            if (keep && pos < DS_SURV) { s_ord[pos] = o4[j]; s_row[pos] = i + j; }
+            surv += __builtin_popcountll(m);
+        }
+    }
+    if (live <= p.kprime && surv <= DS_SURV) {  // every live row is a candidate (kprime <= KPRIME_MAX < DS_SURV)
+        __syncthreads();
+        for (uint32_t e = lane; e < surv; e += 64) {
+            const uint64_t slot = (uint64_t)q * p.kprime + e;
+            p.cand_ids[slot] = s_row[e];
+            if (p.cand_scores) p.cand_scores[slot] = ord2f(s_ord[e]);
+        }
+        if (lane == 0) { p.cand_n[q] = surv; p.tau_star[q] = -INFINITY; }
+        return;
+    }
+    if (surv <= DS_SURV) {
+        for (uint32_t e = surv + lane; e < ((surv + 255u) & ~255u) && e < DS_SURV; e += 64) s_ord[e] = 0u;
+        __syncthreads();
+        const uint32_t kth = wave_kth_largest_u32(s_ord, surv, p.kprime, lane);
+        uint32_t gt = 0;
+        for (uint32_t i = 0; i < surv; i += 64) {
+            const bool g = (i + lane < surv) && (s_ord[i + lane] > kth);
+            gt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(g));
+        }
+        const uint32_t need_ties = p.kprime - gt;  // rows scoring exactly the kprime-th score: the lowest ids win
         uint32_t base = 0;
-        for (uint32_t i = 0; i < p.n; i += 64) {
-            const uint32_t r = i + lane;
-            const uint32_t o = r < p.n ? ord[r] : 0u;
-            const bool keep = o >= 1u;
+        for (uint32_t i = 0; i < surv; i += 64) {
+            const uint32_t e = i + lane;
+            const uint32_t o = e < surv ? s_ord[e] : 0u;
+            const uint32_t row = e < surv ? s_row[e] : 0u;
+            // survivors are not in row order: a tie's rank is the number of ties with a lower row id
+            uint32_t rank = 0;
+            const bool tie = e < surv && o == kth;
+            if (tie)
+                for (uint32_t j = 0; j < surv; ++j) rank += (s_ord[j] == kth && s_row[j] < row) ? 1u : 0u;
+            const bool keep = o > kth || (tie && rank < need_ties);
             const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
             if (keep) {
                 const uint64_t slot = (uint64_t)q * p.kprime + base + __builtin_popcountll(m & lt_mask);
-                p.cand_ids[slot] = r;
+                p.cand_ids[slot] = row;
                 if (p.cand_scores) p.cand_scores[slot] = ord2f(o);
             }
             base += __builtin_popcountll(m);
         }
-        if (lane == 0) { p.cand_n[q] = base; p.tau_star[q] = -INFINITY; }
+        if (lane == 0) { p.cand_n[q] = base; p.tau_star[q] = ord2f(kth); }
         return;
     }
-    // pivot: the kprime-th largest of the lanes' top-T scores (64 T >= kprime of them)
-    uint32_t pivot = 0;
+    // The wide case: more rows at or above the pivot than the LDS holds.  The kprime-th largest score over the whole
+    // row, every bit from a fresh sweep of the scores; then one more sweep in row order, ties to the lowest ids.
+    uint32_t kth = 0;
     for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t trial = pivot | (1u << bit);
+        const uint32_t trial = kth | (1u << bit);
         uint32_t cnt = 0;
+        for (uint32_t i = lane * 4; i < nq4; i += 256) {
+            uint32_t o4[4];
+            dense_ord4(p, sc, i, masked, o4);
 #pragma unroll
-        for (int t = 0; t < DS_T; ++t)
-            cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64((uint32_t)t < T && top[t] >= trial));
-        if (cnt >= p.kprime) pivot = trial;
-    }
-    // rows at or above the pivot, per lane over its own (strided) rows, then compacted
-    uint32_t mine = 0;
-    for (uint32_t r = lane; r < p.n; r += 64) mine += ord[r] >= pivot ? 1u : 0u;
-    uint32_t incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
-        if (lane >= (uint32_t)off) incl += t;
-    }
-    const uint32_t surv = (uint32_t)__shfl((int)incl, 63);
-    const uint32_t* sel_ord = ord;  // what the exact selection runs over
-    uint32_t sel_n = p.n;
-    const bool narrowed = pivot > 0u && surv <= DS_SURV;
-    if (narrowed) {
-        uint32_t w = incl - mine;
-        for (uint32_t r = lane; r < p.n; r += 64) {
-            const uint32_t o = ord[r];
-            if (o >= pivot) { s_ord[w] = o; s_row[w] = r; ++w; }
+            for (int j = 0; j < 4; ++j) cnt += o4[j] >= trial ? 1u : 0u;
         }
-        for (uint32_t e = surv + lane; e < ((surv + 255u) & ~255u) && e < DS_SURV; e += 64) s_ord[e] = 0u;
-        __syncthreads();
-        sel_ord = s_ord;
-        sel_n = surv;
+#pragma unroll
+        for (int off = 32; off; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
+        if (cnt >= p.kprime) kth = trial;
     }
-    const uint32_t kth = wave_kth_largest_u32(sel_ord, sel_n, p.kprime, lane);
     uint32_t gt = 0;
-    for (uint32_t i = 0; i < sel_n; i += 64) {
-        const bool g = (i + lane < sel_n) && (sel_ord[i + lane] > kth);
-        gt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(g));
+    for (uint32_t i = lane * 4; i < nq4; i += 256) {
+        uint32_t o4[4];
+        dense_ord4(p, sc, i, masked, o4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gt += o4[j] > kth ? 1u : 0u;
     }
-    const uint32_t need_ties = p.kprime - gt;  // rows scoring exactly the kprime-th score: the lowest ids win
+#pragma unroll
+    for (int off = 32; off; off >>= 1) gt += (uint32_t)__shfl_xor((int)gt, off);
+    const uint32_t need_ties = p.kprime - gt;
     uint32_t base = 0, ties = 0;
-    for (uint32_t i = 0; i < sel_n; i += 64) {
-        const uint32_t e = i + lane;
-        const uint32_t o = e < sel_n ? sel_ord[e] : 0u;
-        const uint32_t row = narrowed ? (e < sel_n ? s_row[e] : 0u) : e;
-        const bool tie = e < sel_n && o == kth;
-        const uint64_t tm = __builtin_amdgcn_ballot_w64(tie);
-        bool keep_tie;
-        if (narrowed) {
-            // survivors are not in row order: a tie's rank is the number of ties with a lower row id
-            uint32_t rank = 0;
-            if (tie)
-                for (uint32_t j = 0; j < sel_n; ++j) rank += (s_ord[j] == kth && s_row[j] < row) ? 1u : 0u;
-            keep_tie = tie && rank < need_ties;
-        } else {
-            keep_tie = tie && ties + __builtin_popcountll(tm & lt_mask) < need_ties;
+    for (uint32_t i = 0; i < p.n; i += 64) {  // row order: lane = row within the chunk
+        const uint32_t r = i + lane;
+        uint32_t o = 0u;
+        if (r < p.n) {
+            bool ok = true;
+            if (masked && p.valid) ok = bit_set(p.valid, r);
+            if (masked && ok && p.filter) ok = bit_set(p.filter, r);
+            o = ok ? f2ord(sc[r]) : 0u;
         }
-        const bool keep = o > kth || keep_tie;
+        const bool tie = o == kth && o != 0u;
+        const uint64_t tm = __builtin_amdgcn_ballot_w64(tie);
+        const bool keep = o > kth || (tie && ties + __builtin_popcountll(tm & lt_mask) < need_ties);
         const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
         if (keep) {
             const uint64_t slot = (uint64_t)q * p.kprime + base + __builtin_popcountll(m & lt_mask);
-            p.cand_ids[slot] = row;
+            p.cand_ids[slot] = r;
             if (p.cand_scores) p.cand_scores[slot] = ord2f(o);
         }
         base += __builtin_popcountll(m);
         ties += __builtin_popcountll(tm);
     }
-    if (lane == 0) {
-        p.cand_n[q] = base;
-        p.tau_star[q] = ord2f(kth);
-    }
+    if (lane == 0) { p.cand_n[q] = base; p.tau_star[q] = ord2f(kth); }
 }
 
 hipError_t launch_dense_select(const PostParams& p, hipStream_t stream) {
     if (p.q == 0) return hipSuccess;
     if (p.n > DENSE_MAX_ROWS || !p.dense_scores || p.kprime == 0) return hipErrorInvalidValue;
-    const size_t lds = (size_t)((p.n + 255u) & ~255u) * sizeof(uint32_t);
-    hipLaunchKernelGGL(dense_select_kernel, dim3(p.q), dim3(64), lds, stream, p);
+    hipLaunchKernelGGL(dense_select_kernel, dim3(p.q), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 

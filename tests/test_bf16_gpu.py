@@ -140,3 +140,30 @@ def test_bf16_ties_masks_and_dimension_beyond_registers(ctx, oracle):
     ix = na.FlatIndex(ctx, base, na.DistanceFunction.Cosine)
     _check(oracle, ix.search(queries, 5, precision="bf16"), base, queries, 5, na.DistanceFunction.Cosine)
     ix.close()
+
+
+def test_small_base_selection_corner_cases(ctx, oracle):
+    """Bases small enough for the dense score matrix: the selection narrows every row of scores to the rows above a
+    pivot.  Here the narrowing cannot work: thousands of rows tie at the top (more survivors than its buffer holds),
+    and masks that leave live rows in a few lanes' columns only (no pivot); both must still return the oracle's rows."""
+    import needle_amd as na
+
+    rng = np.random.default_rng(21)
+    n, dim = 6000, 40
+    base = rng.standard_normal((n, dim)).astype(F)
+    base[500:4500] = base[7]                      # 4000 identical rows: ties broken by id
+    queries = rng.standard_normal((70, dim)).astype(F)
+    queries[0] = base[7]
+    queries[1] = -base[7]                          # the tied block at the far end
+    for metric in (na.DistanceFunction.Euclidean, na.DistanceFunction.Cosine, na.DistanceFunction.DotProduct):
+        ix = na.FlatIndex(ctx, base, metric)
+        for k in (1, 10, 100):
+            _check(oracle, ix.search(queries, k, precision="bf16"), base, queries, k, metric)
+        # live rows only where row % 256 < 8: two of the selection's 64 lanes see anything
+        keep = (np.arange(n) % 256) < 8
+        for k in (10, 150):
+            _check(oracle, ix.search(queries, k, precision="bf16", filter_mask=keep), base, queries, k, metric, filt=keep)
+        few = np.zeros(n, dtype=bool)
+        few[[3, 4000, 5999]] = True               # fewer live rows than k
+        _check(oracle, ix.search(queries, 10, precision="bf16", filter_mask=few), base, queries, 10, metric, filt=few)
+        ix.close()
