@@ -24,8 +24,11 @@ namespace nh {
 // group would not fit, what has been gathered so far is first cut down to its kprime best (the cut only ever
 // removes keys below the final kprime-th one).
 // ---------------------------------------------------------------------------
-constexpr uint32_t MERGE_KEYS = 2048 + KPRIME_MAX;
-constexpr uint32_t MERGE_FAST_LISTS = 1024;  // lists per query the one-shot gather handles
+// Sizes of a launch (dynamic LDS: 8 bytes per key, 4 per list offset): the smaller they are, the more queries a CU
+// works on at once -- the kernel is a chain of short dependent steps per query, so it lives on occupancy.
+// Measured (10K queries, 64 candidates kept of ~130 listed in 128 lists): 2304 keys + 1024 offsets 0.18 ms,
+// 768 + 256 0.07 ms.  A query that lists more than the buffer holds takes the gather in groups.
+constexpr uint32_t MERGE_KEYS_MAX = 2048 + KPRIME_MAX;
 
 // kprime-th largest of keys[0 .. total) (total >= kprime), found bit by bit; all keys are distinct
 // per-lane counts over pairs of keys (a count does not care which lane sees which key), one cross-lane sum per bit
@@ -48,13 +51,13 @@ __device__ inline uint64_t wave_kth_largest_lds(const uint64_t* keys, uint32_t t
     return prefix;
 }
 
-__global__ __launch_bounds__(64) void merge_select_kernel(PostParams p) {
-    __shared__ __attribute__((aligned(16))) uint64_t mkeys[MERGE_KEYS];
+__global__ __launch_bounds__(64) void merge_select_kernel(PostParams p, uint32_t MERGE_KEYS, uint32_t MERGE_FAST_LISTS) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t mkeys[];  // [MERGE_KEYS], then loff[MERGE_FAST_LISTS + 1]
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
     const uint64_t first = p.list_base ? p.list_base[q] : (uint64_t)q * p.n_splits;
     const uint32_t n_lists = p.list_base ? p.list_base[q + 1] - p.list_base[q] : p.n_splits;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    __shared__ uint32_t loff[MERGE_FAST_LISTS + 1];
+    uint32_t* loff = reinterpret_cast<uint32_t*>(mkeys + MERGE_KEYS);
     uint32_t total = 0;
     bool done = false;
     if (n_lists <= MERGE_FAST_LISTS) {
@@ -154,7 +157,16 @@ __global__ __launch_bounds__(64) void merge_select_kernel(PostParams p) {
 hipError_t launch_merge_select(const PostParams& p, hipStream_t stream) {
     if (p.q == 0) return hipSuccess;
     if (p.kprime == 0 || p.kprime > (uint32_t)KPRIME_MAX) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(merge_select_kernel, dim3(p.q), dim3(64), 0, stream, p);
+    // what a query lists grows with k (k = 100: about a thousand entries); room for them in one gather when it is cheap
+    uint32_t keys = std::min<uint32_t>(MERGE_KEYS_MAX, std::max<uint32_t>(768u, 10u * p.kprime + 128u));
+    // lists per query the one-shot gather handles: all of them for a flat scan (their number is known here)
+    uint32_t fast = p.list_base ? 256u : std::min<uint32_t>(1024u, std::max<uint32_t>(64u, p.n_splits));
+    if (const char* e = getenv("NEEDLE_HIP_DEBUG_MERGE")) {  // development: "keys,lists"
+        unsigned a = 0, b = 0;
+        if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 2u * KPRIME_MAX && a <= 4096 && b >= 1 && b <= 2048) { keys = a / 2 * 2; fast = b; }
+    }
+    const size_t lds = (size_t)keys * sizeof(uint64_t) + ((size_t)fast + 1) * sizeof(uint32_t);
+    hipLaunchKernelGGL(merge_select_kernel, dim3(p.q), dim3(64), lds, stream, p, keys, fast);
     return hipGetLastError();
 }
 
