@@ -558,10 +558,6 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
         if (worst <= max_lists_per_query) break;
     }
     uint32_t bounds[4] = {0, 0, std::min<uint32_t>(4, np), np};  // with seeded thresholds: slots 0-3, refresh, the rest
-    if (const char* dbg = getenv("NEEDLE_HIP_DEBUG_IVF_STAGES")) {  // development: "a,b" = slot bounds of launches 1 and 2
-        unsigned a = 0, b = 0;
-        if (sscanf(dbg, "%u,%u", &a, &b) == 2) { bounds[1] = std::min<uint32_t>(a, np); bounds[2] = std::min<uint32_t>(std::max(a, b), np); }
-    }
     RegroupBufs rg{};
     {
         const uint32_t SL = 3 * ix->nlist;

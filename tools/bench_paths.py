@@ -108,6 +108,8 @@ def concurrent_qps(handle, dq, k, callers, steps, *, nprobe=0, precision="bf16",
     return round(callers * steps * nq / dt, 1)
 
 
+CONCURRENCY = False  # --concurrency: also time 2 and 4 host threads searching one index at once
+
 COLLECT = None  # a list: entries are appended instead of printed (bench.py folds them into its JSON line)
 
 
@@ -185,7 +187,7 @@ def flat_case(ctx, dev, name, n, dim, nq, k, metric, steps, filt_frac=None, orac
         if prec == precisions[0]:
             extra["host_pointer_qps"] = host_api_qps(ix._h, queries.cpu().numpy(), k, precision=prec,
                                                      filt_words=_mask_words(keep, n) if keep is not None else None)
-            if nq <= 2000:  # small batches leave the chip idle between their short kernels: what concurrent callers gain
+            if nq <= 2000 and CONCURRENCY:  # small batches leave the chip idle between their short kernels: what concurrent callers gain
                 extra["concurrent_callers_qps"] = {str(t): concurrent_qps(ix._h, queries, k, t, max(steps, 4), precision=prec,
                                                                           d_filter=d_filter) for t in (2, 4)}
         if oracle is not None:
@@ -252,7 +254,8 @@ def ivf_case(ctx, dev, n, dim, nlist, nprobe, nq, k, steps, oracle=None, centroi
              "roofline": roofline("hbm", bytes_items / sec / 1e9, "GB/s", "ivf list-major scan (whole search)",
                                   "4*D bytes per row of every probed list, once per tile of the queries probing it", sec * 1e3),
              "host_pointer_qps": host_api_qps(h, queries, k, nprobe=nprobe, precision="bf16"),
-             "concurrent_callers_qps": {str(t): concurrent_qps(h, dq, k, t, max(steps, 4), nprobe=nprobe) for t in (2, 4)},
+             "concurrent_callers_qps": ({str(t): concurrent_qps(h, dq, k, t, max(steps, 4), nprobe=nprobe) for t in (2, 4)}
+                                        if CONCURRENCY else None),
              "fp32_list_scan_ms_per_batch": round(sec32 * 1e3, 3), "build_s": round(build_s, 2), "train_s": round(train_s, 2),
              "scanned_pairs": pairs,
              "bytes_listmajor": bytes_items, "bytes_each_probed_list_once": bytes_once, "bytes_unbatched": bytes_unbatched,
@@ -309,7 +312,8 @@ def sq8_case(ctx, dev, n, dim, nq, k, steps, oracle=None):
                  "fallback_per_batch": m["fallback_queries"] / (steps + 1)}
         if prec == "bf16":
             extra["host_pointer_qps"] = host_api_qps(ix._h, queries, k, precision=prec)
-            extra["concurrent_callers_qps"] = {str(t): concurrent_qps(ix._h, dq, k, t, max(steps, 4), precision=prec) for t in (2, 4)}
+            if CONCURRENCY:
+                extra["concurrent_callers_qps"] = {str(t): concurrent_qps(ix._h, dq, k, t, max(steps, 4), precision=prec) for t in (2, 4)}
         if oracle is not None:
             s, ns = 8, 400_000
             small = na.quantization.Sq8Index(ctx, sq, codes[:ns])
@@ -349,7 +353,8 @@ def pq_case(ctx, dev, n, dim, m_sub, nq, k, steps, oracle=None, build_timing=Tru
                      "roofline_mfma": roofline("mfma", 2.0 * nq * n * dim / scan_ms / 1e9, "TFLOP/s", "flat_scan_bf16 over the decoded rows",
                                                "2*Q*N*D flop per batch", scan_ms),
                      "host_pointer_qps": host_api_qps(ix._h, queries, k, precision=prec),
-                     "concurrent_callers_qps": {str(t): concurrent_qps(ix._h, dq, k, t, max(steps, 4), precision=prec) for t in (2, 4)},
+                     "concurrent_callers_qps": ({str(t): concurrent_qps(ix._h, dq, k, t, max(steps, 4), precision=prec) for t in (2, 4)}
+                                                if CONCURRENCY else None),
                      "fallback_per_batch": mm["fallback_queries"] / (steps + 1)}
         else:
             qg = min(3, (150 * 1024) // (m_sub * 1024))
@@ -495,12 +500,15 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the row counts (smoke runs)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--concurrency", action="store_true", help="also time 2 and 4 host threads searching one index at once")
     ap.add_argument("--hnsw-rows", type=int, default=16384, help="rows of the hnsw path's sample (the build is sequential)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--hnsw-data", default="gaussian", choices=["gaussian", "clustered"])
     ap.add_argument("--ivf-centroids", default="trained", choices=["trained", "sampled"],
                     help="trained: Lloyd iterations on a sample (balanced lists); sampled: raw rows (hub lists)")
     args = ap.parse_args()
+    global CONCURRENCY
+    CONCURRENCY = args.concurrency
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     ctx = na.Context(0)
