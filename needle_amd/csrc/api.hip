@@ -174,6 +174,7 @@ void nh::index_free(needle_hip_index* ix) {
     if (ix->d_list_len) (void)hipFree(ix->d_list_len);
     if (ix->d_pos2id) (void)hipFree(ix->d_pos2id);
     if (ix->d_codes) (void)hipFree(ix->d_codes);
+    if (ix->d_codes_gm) (void)hipFree(ix->d_codes_gm);
     if (ix->d_codebooks) (void)hipFree(ix->d_codebooks);
     if (ix->d_sq_min) (void)hipFree(ix->d_sq_min);
     if (ix->d_sq_scale) (void)hipFree(ix->d_sq_scale);
@@ -196,7 +197,7 @@ static void release_workspace(needle_hip_index* ix) {
     for (DevBuf* b : {&ix->w_qraw, &ix->w_qop, &ix->w_qn2, &ix->w_lists, &ix->w_lcnt, &ix->w_cand, &ix->w_candn,
                       &ix->w_tau, &ix->w_flagged, &ix->w_flagcnt, &ix->w_filter, &ix->w_premax, &ix->w_tau0, &ix->x_keys, &ix->x_u32,
                       &ix->x_u64, &ix->x_sel, &ix->x_mask, &ix->v_probe_ids, &ix->v_probe_d, &ix->v_probe_n, &ix->v_probe32,
-                      &ix->v_items, &ix->v_itemq, &ix->v_lbase, &ix->w_qerr, &ix->r_idx, &ix->r_q, &ix->r_ids, &ix->r_dists, &ix->r_cnt, &ix->v_regroup, &ix->b_work, &ix->w_cinit, &ix->w_cscore})
+                      &ix->v_items, &ix->v_itemq, &ix->v_lbase, &ix->w_qerr, &ix->r_idx, &ix->r_q, &ix->r_ids, &ix->r_dists, &ix->r_cnt, &ix->v_regroup, &ix->b_work, &ix->w_cinit, &ix->w_cscore, &ix->w_pqtab})
         b->release();
 }
 
@@ -210,7 +211,7 @@ static void sync_view(needle_hip_index* v, const needle_hip_index* p, needle_hip
     v->d_valid = p->d_valid; v->max_norm = p->max_norm; v->cos_norm_unsafe = p->cos_norm_unsafe;
     v->bf16_extra_slack = p->bf16_extra_slack; v->bf16_err = p->bf16_err;
     v->nlist = p->nlist; v->d_list_pos = p->d_list_pos; v->d_list_len = p->d_list_len; v->d_pos2id = p->d_pos2id;
-    v->d_codes = p->d_codes; v->d_codebooks = p->d_codebooks; v->pq_m = p->pq_m; v->pq_dsub = p->pq_dsub;
+    v->d_codes = p->d_codes; v->d_codes_gm = p->d_codes_gm; v->d_codebooks = p->d_codebooks; v->pq_m = p->pq_m; v->pq_dsub = p->pq_dsub;
     v->bin_words = p->bin_words; v->d_sq_min = p->d_sq_min; v->d_sq_scale = p->d_sq_scale; v->d_sq_inv = p->d_sq_inv;
     v->sq_min_norm = p->sq_min_norm;
     if (first) {  // host-side list geometry: fixed once the index is built

@@ -10,8 +10,6 @@ extern "C" needle_hip_status needle_hip_pq_build(needle_hip_ctx* c, const uint8_
     *out = nullptr;
     if (dim == 0 || m == 0 || dim % m != 0 || !codebooks)
         return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "need codebooks and dim (%u) divisible by the subvector count (%u)", dim, m);
-    if (pq_scan_queries_per_block(m) == 0)
-        return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "%u subvectors: the distance table does not fit on chip", m);
     if (n > 0 && !codes) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "codes is null");
     if (n >= 0xfffffff0ull) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "too many rows");
     HIP_TRY(hipSetDevice(c->device));
@@ -32,6 +30,9 @@ extern "C" needle_hip_status needle_hip_pq_build(needle_hip_ctx* c, const uint8_
     if (e == hipSuccess && n > 0) {
         e = hipMalloc((void**)&ix->d_codes, (size_t)n * m + 16);
         if (e == hipSuccess) e = hipMemcpyAsync(ix->d_codes, codes, (size_t)n * m, hipMemcpyHostToDevice, c->stream);
+        // the same codes, 16 subspaces of a row per 16-byte read, for the distance-table scan
+        if (e == hipSuccess) e = hipMalloc((void**)&ix->d_codes_gm, (size_t)((m + PQ_SG - 1) / PQ_SG) * n * PQ_SG);
+        if (e == hipSuccess) e = launch_pq_group_codes(ix->d_codes, n, m, ix->d_codes_gm, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     needle_hip_status st = NEEDLE_HIP_OK;
@@ -56,60 +57,76 @@ needle_hip_status nh::pq_search_batch_device(needle_hip_index* ix, const float* 
         c->m.fallback_queries += q;
         return NEEDLE_HIP_OK;
     }
-    const uint32_t qg = pq_scan_queries_per_block(ix->pq_m);
-    const uint32_t groups = (q + qg - 1) / qg;
-    // slices of the code matrix: enough workgroups to fill the chip, slices of >= 4096 rows,
-    // and PQ_WAVES * S lists of k entries per query must fit the merge kernel's LDS
-    uint32_t S = std::max<uint32_t>(1, (4u * (uint32_t)c->n_cu + groups - 1) / groups);
-    S = std::min<uint32_t>(S, std::max<uint32_t>(1, n / (1024u * PQ_WAVES)));
-    S = std::min<uint32_t>(S, std::max<uint32_t>(1, 60000u / ((uint32_t)PQ_WAVES * k * (uint32_t)sizeof(uint64_t))));
-    const uint32_t rows_per_split = (n + S - 1) / S;
-    S = (n + rows_per_split - 1) / rows_per_split;
-    const uint32_t lists_per_q = PQ_WAVES * S, cap = 2 * k + 64;
+    // Queries go through in chunks whose interleaved distance tables (1 KB per query and subspace) stay within 1 GB.
+    const uint32_t m = ix->pq_m;
+    const uint32_t q_chunk = std::max<uint32_t>(PQ_QB, (uint32_t)std::min<uint64_t>(16384, (1ull << 30) / ((uint64_t)m * 1024)) / PQ_QB * PQ_QB);
+    const uint32_t cap = 2 * k + 64;
+    for (uint32_t q0 = 0; q0 < q; q0 += q_chunk) {
+        const uint32_t qc = std::min(q_chunk, q - q0);
+        const uint32_t groups = (qc + PQ_QB - 1) / PQ_QB;
+        // Slices of the code matrix: a few whole blocks of rows each, PQ_WAVES * S lists of k entries per query within the
+        // merge kernel's LDS, and S * groups workgroups filling the chip in whole rounds (the smallest S that wastes
+        // less than a tenth of the last round, else the best found).
+        uint32_t s_max = std::max<uint32_t>(1, n / (4 * pq_scan_block_rows()));
+        s_max = std::min<uint32_t>(s_max, std::max<uint32_t>(1, 60000u / ((uint32_t)PQ_WAVES * k * (uint32_t)sizeof(uint64_t))));
+        uint32_t S = 1;
+        double best = 0.0;
+        for (uint32_t s = 1; s <= s_max; ++s) {
+            const uint32_t wgs = s * groups, rounds = (wgs + (uint32_t)c->n_cu - 1) / (uint32_t)c->n_cu;
+            const double fill = (double)wgs / ((double)rounds * c->n_cu);
+            if (fill > best + 1e-9) { best = fill; S = s; }
+            if (fill >= 0.9) { S = s; break; }
+        }
+        const uint32_t rows_per_split = (n + S - 1) / S;
+        S = (n + rows_per_split - 1) / rows_per_split;
+        const uint32_t lists_per_q = PQ_WAVES * S;
 
-    HIP_TRY(ix->w_lists.ensure((size_t)q * lists_per_q * cap * sizeof(uint2)));
-    HIP_TRY(ix->w_lcnt.ensure((size_t)q * lists_per_q * sizeof(uint32_t)));
-    HIP_TRY(ix->w_cand.ensure((size_t)q * k * sizeof(uint32_t)));
-    HIP_TRY(ix->w_scores.ensure((size_t)q * k * sizeof(float)));
-    HIP_TRY(ix->w_candn.ensure((size_t)q * sizeof(uint32_t)));
-    HIP_TRY(ix->w_tau.ensure((size_t)q * sizeof(float)));
-    HIP_TRY(hipMemsetAsync(ix->w_lcnt.p, 0, (size_t)q * lists_per_q * sizeof(uint32_t), c->stream));
+        HIP_TRY(ix->w_pqtab.ensure((size_t)groups * m * 2 * 256 * 4 * sizeof(float)));
+        HIP_TRY(ix->w_lists.ensure((size_t)qc * lists_per_q * cap * sizeof(uint2)));
+        HIP_TRY(ix->w_lcnt.ensure((size_t)qc * lists_per_q * sizeof(uint32_t)));
+        HIP_TRY(ix->w_cand.ensure((size_t)qc * k * sizeof(uint32_t)));
+        HIP_TRY(ix->w_scores.ensure((size_t)qc * k * sizeof(float)));
+        HIP_TRY(ix->w_candn.ensure((size_t)qc * sizeof(uint32_t)));
+        HIP_TRY(ix->w_tau.ensure((size_t)qc * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(ix->w_lcnt.p, 0, (size_t)qc * lists_per_q * sizeof(uint32_t), c->stream));
 
-    PqScanParams sp{};
-    sp.codes = ix->d_codes;
-    sp.codebooks = ix->d_codebooks;
-    sp.queries = d_queries;
-    sp.valid = ix->d_valid;
-    sp.filter = d_filter;
-    sp.lists = ix->w_lists.as<uint2>();
-    sp.list_counts = ix->w_lcnt.as<uint32_t>();
-    sp.n = n; sp.m = ix->pq_m; sp.dsub = ix->pq_dsub; sp.dim = ix->dim; sp.q = q; sp.qg = qg;
-    sp.n_splits = S; sp.rows_per_split = rows_per_split; sp.k = k; sp.cap = cap;
-    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    HIP_TRY(launch_pq_scan(sp, c->stream));
-    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        PqScanParams sp{};
+        sp.codes_gm = ix->d_codes_gm;
+        sp.tables = ix->w_pqtab.as<float>();
+        sp.valid = ix->d_valid;
+        sp.filter = d_filter;
+        sp.lists = ix->w_lists.as<uint2>();
+        sp.list_counts = ix->w_lcnt.as<uint32_t>();
+        sp.n = n; sp.m = m; sp.n_sg = (m + PQ_SG - 1) / PQ_SG; sp.q = qc;
+        sp.n_splits = S; sp.rows_per_split = rows_per_split; sp.k = k; sp.cap = cap;
+        if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        HIP_TRY(launch_pq_tables(d_queries + (size_t)q0 * ix->dim, ix->d_codebooks, qc, m, ix->pq_dsub, ix->dim, ix->w_pqtab.as<float>(),
+                                 c->stream));
+        HIP_TRY(launch_pq_scan(sp, c->stream));
+        if (c->profiling) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
 
-    PostParams pp{};
-    pp.lists = sp.lists;
-    pp.list_counts = sp.list_counts;
-    pp.cand_ids = ix->w_cand.as<uint32_t>();
-    pp.cand_scores = ix->w_scores.as<float>();
-    pp.cand_n = ix->w_candn.as<uint32_t>();
-    pp.tau_star = ix->w_tau.as<float>();
-    pp.out_ids = d_out_ids;
-    pp.out_dists = d_out_dists;
-    pp.out_counts = d_out_counts;
-    pp.q = q; pp.n = n; pp.dim = ix->dim; pp.k = k; pp.kprime = k; pp.cap = cap; pp.n_splits = lists_per_q;
-    HIP_TRY(launch_merge_select(pp, c->stream));
-    HIP_TRY(launch_emit_sorted(pp, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->profiling) {
-        float ms = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-        std::lock_guard<std::mutex> g(c->mu);
-        c->m.scan_launches += 1;
-        c->m.scan_ms_total += ms;
-        c->m.last_scan_ms = ms;
+        PostParams pp{};
+        pp.lists = sp.lists;
+        pp.list_counts = sp.list_counts;
+        pp.cand_ids = ix->w_cand.as<uint32_t>();
+        pp.cand_scores = ix->w_scores.as<float>();
+        pp.cand_n = ix->w_candn.as<uint32_t>();
+        pp.tau_star = ix->w_tau.as<float>();
+        pp.out_ids = d_out_ids + (size_t)q0 * k;
+        pp.out_dists = d_out_dists + (size_t)q0 * k;
+        pp.out_counts = d_out_counts + q0;
+        pp.q = qc; pp.n = n; pp.dim = ix->dim; pp.k = k; pp.kprime = k; pp.cap = cap; pp.n_splits = lists_per_q;
+        HIP_TRY(launch_merge_select(pp, c->stream));
+        HIP_TRY(launch_emit_sorted(pp, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->profiling) {
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+            std::lock_guard<std::mutex> g(c->mu);
+            c->m.scan_launches += 1;
+            c->m.scan_ms_total += ms;
+            c->m.last_scan_ms = ms;
+        }
     }
     return NEEDLE_HIP_OK;
 }

@@ -117,6 +117,7 @@ struct needle_hip_index {
     uint32_t* d_pos2id = nullptr;  // [n_pad] row id of a position, ~0 for padding
     // quantized code matrices
     uint8_t* d_codes = nullptr;    // PQ: [n][pq_m]; SQ8: [n_pad][dpad_f32] zero padded
+    uint8_t* d_codes_gm = nullptr; // PQ index: the codes again as [ceil(pq_m / 16)][n][16] for the distance-table scan
     float* d_codebooks = nullptr;  // PQ: [pq_m][256][pq_dsub]
     uint32_t pq_m = 0, pq_dsub = 0;
     uint32_t bin_words = 0;        // binary codes: 64-bit words per row; d_codes holds [bin_words][n_pad] words, d_sq_min the thresholds
@@ -134,6 +135,7 @@ struct needle_hip_index {
     nh::DevBuf r_idx, r_q, r_ids, r_dists, r_cnt;  // queries a reduced-precision pass could not decide, re-run in fp32
     nh::DevBuf x_keys, x_u32, x_u64, x_sel, x_mask;
     nh::DevBuf v_probe_ids, v_probe_d, v_probe_n, v_probe32, v_items, v_itemq, v_lbase, v_regroup;
+    nh::DevBuf w_pqtab; // PQ table scan: interleaved distance tables of a chunk of queries
     nh::DevBuf b_work;  // binary scan: query codes, histograms, tie counts, collected keys
     // Re-entrant searches: every batch search runs on a search slot -- a view of this index (same resident data, its
     // own workspace buffers) bound to a context of its own (own stream, events, metrics).  Slots are created on demand,
