@@ -471,8 +471,11 @@ __device__ inline void push_lane16(const f32x4 (&acc)[4], uint32_t row_base, uin
 // NTQ query tiles of 16 per wave, KS32 k-steps of 32 dims (dpad = 32 * KS32), WAVES waves per workgroup (4: one per
 // SIMD with the whole register file; 8: two per SIMD, so that one wave's selection and list pushes run beside the
 // other's MFMAs).  Queries per workgroup = 16 * NTQ * WAVES.
+#ifndef BF_FLAT_WG4X2
+#define BF_FLAT_WG4X2 0  // 1: dimensions up to 384 run two workgroups of four waves (32 queries each) per CU instead of one of eight
+#endif
 template <int MODE, int NTQ, int KS32, bool CINIT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void flat_scan_bf16x_kernel(ScanParams p) {
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 8 || (BF_FLAT_WG4X2 && KS32 <= 12)) ? 2 : 1) void flat_scan_bf16x_kernel(ScanParams p) {
     constexpr int CSLOT = 256 * WAVES;   // per slot: the half tile's accumulator seeds, once per wave
     constexpr int PIECES = 16 / WAVES;   // fill pieces (4 rows x 256 B) a wave issues per stage
     __shared__ __attribute__((aligned(1024))) unsigned char smem[BF_NBUF * (BF_STAGE_BYTES + CSLOT)];
@@ -768,7 +771,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void flat_scan_bf16x_kernel(
 #define BF_WAVES8 1  // 1: dimensions up to 384 run eight waves of 32 queries per workgroup; 0: four waves of 64
 #endif
 uint32_t flat_scan_bf16_lists_per_slice() { return BF_MF16 ? 4 : 2; }
-constexpr int BF_NTQ = BF_WAVES8 ? 2 : 4, BF_NW = BF_WAVES8 ? 8 : 4;
+constexpr int BF_NTQ = (BF_WAVES8 || BF_FLAT_WG4X2) ? 2 : 4, BF_NW = (BF_WAVES8 && !BF_FLAT_WG4X2) ? 8 : 4;
 
 // dpad (dims padded to a supported k-step count) and queries per workgroup for a dimension; 0 = unsupported
 uint32_t flat_scan_bf16_dpad(uint32_t dim) {
@@ -780,7 +783,7 @@ uint32_t flat_scan_bf16_dpad(uint32_t dim) {
     if (ks <= 48) return 768;
     return 0;
 }
-uint32_t flat_scan_bf16_queries_per_block(uint32_t dpad) { return dpad <= 384 ? 256 : 128; }
+uint32_t flat_scan_bf16_queries_per_block(uint32_t dpad) { return (dpad <= 384 && BF_MF16) ? 16u * BF_NTQ * BF_NW : (dpad <= 384 ? 256u : 128u); }
 #ifndef BF_IVF_WAVES
 #define BF_IVF_WAVES 4  // waves per workgroup of the inverted-list scan up to 384 dimensions: 128 query slots per work item, two
                         // items per CU (measured 2.5 % faster than 8 waves / 256 slots at nlist 4096, nprobe 32, 10K queries)
