@@ -677,7 +677,7 @@ needle_hip_status nh::ensure_bf16_copy(needle_hip_index* ix) {
 // Device-resident search of one batch of at most QB queries.
 needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k,
                                                int precision, const uint32_t* d_filter, uint64_t* d_out_ids,
-                                               float* d_out_dists, uint32_t* d_out_counts) {
+                                               float* d_out_dists, uint32_t* d_out_counts, bool set_only) {
     needle_hip_ctx* c = ix->ctx;
     const uint32_t n = (uint32_t)ix->n;
     const bool sq8 = ix->kind == KIND_SQ8;
@@ -924,8 +924,12 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     } else {
         HIP_TRY(launch_merge_select(pp, c->stream));
     }
-    if (prune) HIP_TRY(launch_prune_candidates(pp, band, c->stream));
-    HIP_TRY(launch_rescore_finalize(pp, c->stream));
+    // set_only (the probe step of an inverted-file search): the caller needs the k nearest rows as a set, so only the
+    // candidates whose first-pass scores leave their membership open are re-scored
+    const bool set_mode = set_only && dense && prune && bf16 && !sq8 && ix->kind == KIND_FLAT && ix->metric == NEEDLE_METRIC_EUCLIDEAN &&
+                          !getenv("NEEDLE_HIP_DEBUG_NOSETONLY");
+    if (prune && !set_mode) HIP_TRY(launch_prune_candidates(pp, band, c->stream));
+    HIP_TRY(launch_rescore_finalize(pp, c->stream, set_mode ? &band : nullptr));
 
     uint32_t n_flagged = 0;
     HIP_TRY(hipMemcpyAsync(&n_flagged, pp.flag_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));

@@ -456,7 +456,8 @@ extern "C" needle_hip_status needle_hip_ivf_list_sizes(const needle_hip_index* i
 }
 
 // Coarse step on device-resident queries: v_probe32 [q][np] list ids (u32), v_probe_n [q].
-static needle_hip_status ivf_probe_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t np) {
+// set_only: the lists in any order (the search regroups them by list); otherwise ascending by (distance, list).
+static needle_hip_status ivf_probe_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t np, bool set_only) {
     needle_hip_ctx* c = ix->ctx;
     HIP_TRY(ix->v_probe_ids.ensure((size_t)q * np * sizeof(uint64_t)));
     HIP_TRY(ix->v_probe_d.ensure((size_t)q * np * sizeof(float)));
@@ -468,7 +469,7 @@ static needle_hip_status ivf_probe_device(needle_hip_index* ix, const float* d_q
         // (an fp32 first pass over a few thousand centroids measured slower: 5.3 against 3.9 ms per 10K-query batch)
         ST_TRY(flat_search_batch_device(ix->centroids, d_queries, q, np, NEEDLE_PRECISION_BF16, nullptr,
                                         ix->v_probe_ids.as<uint64_t>(), ix->v_probe_d.as<float>(),
-                                        ix->v_probe_n.as<uint32_t>()));
+                                        ix->v_probe_n.as<uint32_t>(), set_only));
     }
     const uint32_t total = q * np;
     hipLaunchKernelGGL(ivf_narrow_probe_kernel, dim3((total + 255) / 256), dim3(256), 0, c->stream,
@@ -493,7 +494,7 @@ extern "C" needle_hip_status needle_hip_ivf_probe(needle_hip_index* ix, const fl
     if (np > K_MAX) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "nprobe = %u exceeds %d", np, K_MAX);
     HIP_TRY(ix->w_qraw.ensure((size_t)q * ix->dim * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(ix->w_qraw.p, queries, (size_t)q * ix->dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    ST_TRY(ivf_probe_device(ix, ix->w_qraw.as<float>(), q, np));
+    ST_TRY(ivf_probe_device(ix, ix->w_qraw.as<float>(), q, np, false));
     std::vector<uint32_t> tmp((size_t)q * np);
     HIP_TRY(hipMemcpyAsync(tmp.data(), ix->v_probe32.p, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(out_counts, ix->v_probe_n.p, (size_t)q * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -516,7 +517,7 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
         return NEEDLE_HIP_OK;
     }
     if (np > K_MAX) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "nprobe = %u exceeds %d", np, K_MAX);
-    ST_TRY(ivf_probe_device(ix, d_queries, q, np));
+    ST_TRY(ivf_probe_device(ix, d_queries, q, np, true));
     const uint32_t* d_probe = ix->v_probe32.as<uint32_t>();
     const uint32_t* d_probe_n = ix->v_probe_n.as<uint32_t>();
 

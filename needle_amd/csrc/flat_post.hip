@@ -607,6 +607,27 @@ __device__ inline void ref_accumulate(RefAcc& s, const float* qs, const float* b
     }
 }
 
+// The walk over a staged segment, 16 dimensions at a time: the values are fetched with 16-byte LDS reads into registers
+// first (eight reads in flight), then folded in order -- a loop that reads LDS element by element waits out one LDS
+// latency per dimension.  qs and bs are 16-byte aligned, i0 a multiple of 4.
+template <int KIND>
+__device__ inline void ref_accumulate_staged(RefAcc& s, const float* qs, const float* bs, uint32_t i0, uint32_t i1, uint32_t dim) {
+    const uint32_t len = i1 - i0;
+    uint32_t i = 0;
+    for (; i + 16 <= len; i += 16) {
+        float qv[16], bv[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 a = *(const f32x4*)(qs + i + 4 * t);
+            const f32x4 b = *(const f32x4*)(bs + i + 4 * t);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { qv[4 * t + e] = a[e]; bv[4 * t + e] = b[e]; }
+        }
+        ref_accumulate<KIND>(s, qv, bv, i0 + i, i0 + i + 16, dim);
+    }
+    if (i < len) ref_accumulate<KIND>(s, qs + i, bs + i, i0 + i, i1, dim);
+}
+
 __device__ inline float ref_finish(int kind, const RefAcc& s) {
     switch (kind) {
     case RK_SV_COS: {  // gpu_kernels.rs:348-349
@@ -635,13 +656,34 @@ constexpr int RS_THREADS = 256;
 #define RS_UNROLL 8  // candidate rows a wave has in flight while staging (4: 2.5 % slower on the filtered 768-d search, 16: slower everywhere)
 #endif
 
-__global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams p, uint32_t dc) {
-    extern __shared__ __attribute__((aligned(16))) float stage[];  // [dc] query block, then [nc][dc + 1] row blocks
+// SET_ONLY (Euclidean rows, candidates with their first-pass scores): the caller wants the SET of the k nearest rows,
+// not their order or distances (the probe step of an inverted-file search).  With s_k, s_k+1 the k-th and (k+1)-th
+// largest candidate scores and m = set_margin (score uncertainty on both sides + the reference's own rounding),
+//   * a row scoring below s_k - m has a larger reference distance than each of the k rows scoring >= s_k: it is out
+//     (candidates, and -- through tau* < s_k - m, else the query is flagged -- every row that is no candidate);
+//   * a candidate scoring above s_k+1 + m has a smaller reference distance than every row scoring <= s_k+1, so
+//     fewer than k rows precede it: it is in, with no exact distance computed;
+//   * the candidates in between are re-scored exactly and the best (k - certain) of them by (distance, id) join.
+// Output: the ids in out_ids (certain ones by descending score, then the chosen ones by distance), distances unset.
+__device__ inline double set_margin(const TauBand& band, uint32_t q) {
+    const double u = 5.9604644775390625e-08;
+    const double gam = 2.0 * ((double)band.dim + 16.0) * u;
+    const double qn = sqrt(band.qn2[q]), s = qn + band.bmax;
+    // |score - (q.b - |b|^2/2)| <= eps for both rows; d_ref within (1 +- gam) of the true distance, d^2 <= (|q| + |b|)^2
+    return 2.0 * band_eps(band, q) + 2.05 * gam * s * s;
+}
+
+template <bool SET_ONLY>
+__global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams p, uint32_t dc, uint32_t rcap, TauBand band) {
+    extern __shared__ __attribute__((aligned(16))) float stage[];  // [dc] query block, then [rcap][dc + 4] row blocks
     __shared__ uint64_t skey[KPRIME_MAX];
     __shared__ uint32_t spos[KPRIME_MAX];
+    __shared__ uint32_t s_ord[SET_ONLY ? KPRIME_MAX : 1];
+    __shared__ uint32_t s_misc[4];  // SET_ONLY: ordinals of s_k and s_k+1, number of certain / in-between candidates
     const uint32_t q = blockIdx.x, j = threadIdx.x;
-    const uint32_t nc = min(p.cand_n[q], p.kprime);
+    uint32_t nc = min(p.cand_n[q], p.kprime);
     const uint32_t k_eff = min(p.k, nc);
+    uint32_t emit = k_eff, emit_base = 0;  // hits still to be chosen by exact distance, and their first output slot
     uint64_t key = ~0ull;
     float d = 0.0f;
     uint32_t id = 0, pos = 0;
@@ -650,6 +692,70 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams
         id = p.pos2id ? p.pos2id[pos] : pos;
     }
     if (j < KPRIME_MAX) spos[j] = pos;
+    if (SET_ONLY) {
+        const uint32_t ord = j < nc ? f2ord(p.cand_scores[(uint64_t)q * p.kprime + j]) : 0u;
+        if (j < KPRIME_MAX) s_ord[j] = ord;
+        if (j < 4) s_misc[j] = 0u;
+        __syncthreads();
+        uint32_t srank = 0;  // rank by (score descending, position ascending)
+        if (j < nc)
+            // eight entries per step, their LDS reads in flight together (entries past nc hold ordinal 0: never counted)
+            for (uint32_t i0 = 0; i0 < nc; i0 += 8) {
+                uint32_t o8[8], p8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { o8[u] = s_ord[i0 + u]; p8[u] = spos[i0 + u]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) srank += (o8[u] > ord || (o8[u] == ord && p8[u] < pos)) ? 1u : 0u;
+            }
+        if (j < nc && nc >= p.k && srank + 1 == p.k) s_misc[0] = ord;
+        if (j < nc && srank == p.k) s_misc[1] = ord;
+        __syncthreads();
+        const double m = set_margin(band, q);
+        const float tau = p.tau_star[q];
+        bool ok = (m == m) && m < 1e300 && (tau == tau);
+        int cls = 0;  // 2: certainly a hit, 1: decided by its exact distance, 0: out
+        if (nc < p.k) {  // fewer candidates than hits wanted: they are all hits, provided every live row is a candidate
+            ok = ok && tau == -INFINITY;
+            cls = j < nc ? 1 : 0;
+        } else {
+            const double lo = (double)ord2f(s_misc[0]) - m;
+            ok = ok && (tau == -INFINITY || (double)tau < lo);
+            if (j < nc) {
+                const double sc = (double)ord2f(ord);
+                cls = sc < lo ? 0 : 1;
+                if (nc > p.k && sc > (double)ord2f(s_misc[1]) + m) cls = 2;
+            }
+        }
+        if (cls == 2) atomicAdd(&s_misc[2], 1u);
+        if (cls == 1) atomicAdd(&s_misc[3], 1u);
+        __syncthreads();
+        if (!ok) {  // block-uniform: the exact scan decides this query
+            if (j == 0) p.flagged[atomicAdd(p.flag_count, 1u)] = q;
+            return;
+        }
+        const uint32_t n_certain = s_misc[2], n_open = s_misc[3];
+        emit = k_eff - n_certain;  // certain candidates hold the first n_certain score ranks, so n_certain <= k
+        emit_base = n_certain;
+        if (cls == 2) p.out_ids[(uint64_t)q * p.k + srank] = id;
+        if (emit == n_open || emit == 0) {
+            // the in-between candidates all join (they follow the certain ones in score rank), or none is needed
+            if (cls == 1 && emit != 0) p.out_ids[(uint64_t)q * p.k + srank] = id;
+            for (uint32_t r = k_eff + j; r < p.k; r += blockDim.x) {
+                p.out_ids[(uint64_t)q * p.k + r] = ~0ull;
+                p.out_dists[(uint64_t)q * p.k + r] = INFINITY;
+            }
+            if (j == 0) p.out_counts[q] = k_eff;
+            return;
+        }
+        // the in-between candidates, compacted in score order, are the rows the exact pass walks
+        if (cls == 1) { skey[srank - n_certain] = ((uint64_t)id << 32) | pos; }
+        __syncthreads();
+        nc = n_open;
+        pos = 0; id = 0;
+        if (j < nc) { pos = (uint32_t)skey[j]; id = (uint32_t)(skey[j] >> 32); }
+        __syncthreads();
+        if (j < KPRIME_MAX) spos[j] = pos;
+    }
     if (p.pq_codes) {
         if (j < nc)
             d = canon_distance(p.pq_asym ? exact_pq_asym(p.query_raw + (uint64_t)q * p.dim, p.pq_codes + (uint64_t)pos * p.pq_m,
@@ -667,9 +773,13 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams
         acc.a = zero; acc.b = zero; acc.c = zero;
         float* qs = stage;
         float* rows = stage + dc;
-        const uint32_t ld = dc + 1;  // odd stride: thread j's walk over row j is bank-conflict free
+        const uint32_t ld = dc + 4;  // rows 16-byte aligned, 4 banks apart: the 16-byte reads of thread j's walk over row j are conflict free
         const uint32_t wave = j >> 6, lane = j & 63;
         const float* qsrc = p.query_raw + (uint64_t)q * p.dim;
+        // rcap candidate rows are staged at a time (the LDS image is sized for rcap rows): thread j's candidate belongs to
+        // exactly one such group, so its running sums live through that group's pass over the dimensions only
+        for (uint32_t g0 = 0; g0 < nc; g0 += rcap) {
+        const uint32_t gn = min(rcap, nc - g0);
         for (uint32_t c0 = 0; c0 < p.dim; c0 += dc) {
             const uint32_t len = min(dc, p.dim - c0);
             __syncthreads();  // the previous block has been consumed (and spos is visible)
@@ -677,36 +787,37 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams
             // a wave stages rows wave, wave + 4, ...: RS_UNROLL rows (two loads each per lane, dc <= 128) are in flight before
             // the first LDS store, so the gather is bound by bandwidth rather than by one row's latency at a time
             constexpr uint32_t RS_WAVES = RS_THREADS / 64;
-            for (uint32_t r0 = wave; r0 < nc; r0 += RS_WAVES * RS_UNROLL) {
+            for (uint32_t r0 = wave; r0 < gn; r0 += RS_WAVES * RS_UNROLL) {
                 float v[RS_UNROLL][2];
 #pragma unroll
                 for (uint32_t u = 0; u < RS_UNROLL; ++u) {
-                    const uint32_t r = min(r0 + RS_WAVES * u, nc - 1);
-                    const float* src = p.base_raw + (uint64_t)spos[r] * p.dim + c0;
+                    const uint32_t r = min(r0 + RS_WAVES * u, gn - 1);
+                    const float* src = p.base_raw + (uint64_t)spos[g0 + r] * p.dim + c0;
                     v[u][0] = lane < len ? src[lane] : 0.0f;
                     v[u][1] = lane + 64 < len ? src[lane + 64] : 0.0f;
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < RS_UNROLL; ++u) {
                     const uint32_t r = r0 + RS_WAVES * u;
-                    if (r < nc) {
+                    if (r < gn) {
                         if (lane < len) rows[r * ld + lane] = v[u][0];
                         if (lane + 64 < len) rows[r * ld + lane + 64] = v[u][1];
                     }
                 }
             }
             __syncthreads();
-            if (j < nc) {
-                const float* bs = rows + j * ld;
+            if (j >= g0 && j < g0 + gn) {
+                const float* bs = rows + (j - g0) * ld;
                 switch (kind) {
-                case RK_RS_COS: ref_accumulate<RK_RS_COS>(acc, qs, bs, c0, c0 + len, p.dim); break;
-                case RK_RS_DOT: ref_accumulate<RK_RS_DOT>(acc, qs, bs, c0, c0 + len, p.dim); break;
-                case RK_RS_L2: ref_accumulate<RK_RS_L2>(acc, qs, bs, c0, c0 + len, p.dim); break;
+                case RK_RS_COS: ref_accumulate_staged<RK_RS_COS>(acc, qs, bs, c0, c0 + len, p.dim); break;
+                case RK_RS_DOT: ref_accumulate_staged<RK_RS_DOT>(acc, qs, bs, c0, c0 + len, p.dim); break;
+                case RK_RS_L2: ref_accumulate_staged<RK_RS_L2>(acc, qs, bs, c0, c0 + len, p.dim); break;
                 case RK_C4_COS: ref_accumulate<RK_C4_COS>(acc, qs, bs, c0, c0 + len, p.dim); break;
                 case RK_C4_DOT: ref_accumulate<RK_C4_DOT>(acc, qs, bs, c0, c0 + len, p.dim); break;
                 default: ref_accumulate<RK_C4_L2>(acc, qs, bs, c0, c0 + len, p.dim); break;
                 }
             }
+        }
         }
         if (j < nc) {
             float v = ref_finish(kind, acc);
@@ -720,12 +831,18 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams
     __syncthreads();
     if (j < nc) {
         uint32_t rank = 0;
-        for (uint32_t i = 0; i < nc; ++i) rank += (skey[i] < key) ? 1u : 0u;
-        if (rank < k_eff) {
-            p.out_ids[(uint64_t)q * p.k + rank] = id;
-            p.out_dists[(uint64_t)q * p.k + rank] = d;
+        for (uint32_t i0 = 0; i0 < nc; i0 += 8) {  // entries past nc hold the largest key
+            uint64_t k8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) k8[u] = skey[i0 + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank += (k8[u] < key) ? 1u : 0u;
         }
-        if (rank + 1 == k_eff) {
+        if (rank < emit) {
+            p.out_ids[(uint64_t)q * p.k + emit_base + rank] = id;
+            p.out_dists[(uint64_t)q * p.k + emit_base + rank] = d;
+        }
+        if (!SET_ONLY && rank + 1 == k_eff) {
             const bool ok = p.sq_codes
                                 ? bound_check_sq8(p.tau_star[q], d, p.qnorm2[q], (double)p.max_norm, (double)p.aux_norm, p.dim,
                                                   p.qaux ? 1.000001 * sqrt(p.qaux[q]) * p.berr : 0.0)
@@ -743,19 +860,29 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams
     if (j == 0) p.out_counts[q] = k_eff;
 }
 
-hipError_t launch_rescore_finalize(const PostParams& p, hipStream_t stream) {
+hipError_t launch_rescore_finalize(const PostParams& p, hipStream_t stream, const TauBand* set_only_band) {
     if (p.q == 0) return hipSuccess;
-    // block of dimensions staged at a time: a multiple of 4 (groups of four never straddle blocks), the
-    // row blocks of all kprime candidates within 48 KB
-    uint32_t dc = (48u * 1024u / 4u) / p.kprime;
-    dc = dc > 65 ? 64 : ((dc - 1) / 4) * 4;  // 64 at most: smaller workgroup images, more of them per CU (measured best of 32 .. 128)
-    if (dc < 4) dc = 4;
+    if (set_only_band && (p.metric != NEEDLE_METRIC_EUCLIDEAN || !p.cand_scores || p.sq_codes || p.pq_codes || p.pos2id))
+        return hipErrorInvalidValue;
+    // Rows staged at a time (rcap) and block of dimensions per stage (dc, a multiple of 4: groups of four never straddle
+    // blocks).  A workgroup is a chain of dependent gathers, so what counts is how many of them a CU holds: the image is
+    // kept near 16 KB (64 rows x 64 dimensions measured best of 32 .. 128 dimensions with every candidate staged at once).
+    // After pruning a query rarely keeps more than 64 candidates; the set-only form re-scores a dozen.
+    uint32_t rcap = std::min<uint32_t>(p.kprime, set_only_band ? 32u : 64u);
+    uint32_t dc = set_only_band ? 128u : 64u;
+    if (const char* e = getenv("NEEDLE_HIP_DEBUG_RSCAP")) {  // development: rows staged at a time
+        const uint32_t v = (uint32_t)atoi(e);
+        if (v >= 4 && v <= p.kprime) rcap = v;
+    }
     if (const char* e = getenv("NEEDLE_HIP_DEBUG_RSDC")) {  // development: dimensions staged per block
         const uint32_t v = (uint32_t)atoi(e) / 4 * 4;
-        if (v >= 4 && v <= dc) dc = v;
+        if (v >= 4 && v <= 128) dc = v;
     }
-    const size_t lds = ((size_t)dc + (size_t)p.kprime * (dc + 1)) * sizeof(float);
-    hipLaunchKernelGGL(rescore_finalize_kernel, dim3(p.q), dim3(RS_THREADS), lds, stream, p, dc);
+    const size_t lds = ((size_t)dc + (size_t)rcap * (dc + 4)) * sizeof(float);
+    if (set_only_band)
+        hipLaunchKernelGGL(rescore_finalize_kernel<true>, dim3(p.q), dim3(RS_THREADS), lds, stream, p, dc, rcap, *set_only_band);
+    else
+        hipLaunchKernelGGL(rescore_finalize_kernel<false>, dim3(p.q), dim3(RS_THREADS), lds, stream, p, dc, rcap, TauBand{});
     return hipGetLastError();
 }
 

@@ -174,7 +174,7 @@ void free_search_slots(needle_hip_index* ix);
 // flat search of one batch (api.hip); used by the IVF probe step as well
 needle_hip_status flat_search_batch_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k,
                                            int precision, const uint32_t* d_filter, uint64_t* d_out_ids,
-                                           float* d_out_dists, uint32_t* d_out_counts);
+                                           float* d_out_dists, uint32_t* d_out_counts, bool set_only = false);
 // exact scan of f_total slots; IVF: d_probe/d_probe_n name the lists each query may draw rows from
 needle_hip_status run_exact(needle_hip_index* ix, const float* d_queries, const uint32_t* d_qsel, uint32_t f_total,
                             uint32_t k, const uint32_t* d_filter, uint64_t* d_out_ids, float* d_out_dists,

@@ -138,7 +138,9 @@ hipError_t launch_merge_select(const PostParams& p, hipStream_t stream);
 constexpr uint32_t DENSE_MAX_ROWS = 8192;
 hipError_t launch_dense_select(const PostParams& p, hipStream_t stream);
 hipError_t launch_dense_scores_bf16(const ScanParams& p, hipStream_t stream);
-hipError_t launch_rescore_finalize(const PostParams& p, hipStream_t stream);
+// set_only_band (Euclidean flat rows, cand_scores present, no pruning before): only the SET of the k nearest rows is
+// wanted -- candidates the first-pass scores already decide are not re-scored; ids unordered, distances unset
+hipError_t launch_rescore_finalize(const PostParams& p, hipStream_t stream, const TauBand* set_only_band = nullptr);
 // For scans whose scores ARE the reference distances (score = -distance): rank the merged
 // candidates by (distance, id) and emit the k best.  Needs cand_scores.
 hipError_t launch_emit_sorted(const PostParams& p, hipStream_t stream);

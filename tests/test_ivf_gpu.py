@@ -268,3 +268,42 @@ def test_ivf_pq_lists(ctx, oracle, shape):
         c = int(oc[i])
         assert np.array_equal(ids[i, :c], oi[i, :c]) and np.array_equal(dists[i, :c].view(np.uint32), od[i, :c].view(np.uint32))
     ix.close()
+
+
+@pytest.mark.parametrize("case", ["duplicates", "near_ties", "nprobe_ge_nlist", "many_lists"])
+def test_probe_set_decided_by_scores(ctx, oracle, case):
+    """The search needs the probed lists as a SET: centroids whose first-pass score decides their membership are not
+    re-scored, the ones near the nprobe-th are (flat_post.hip, set-only re-score).  Centroid sets that put many
+    centroids at or next to the boundary -- exact duplicates, copies differing in the last bits, fewer lists than
+    probes, and thousands of lists -- must give the oracle's hits all the same (ivf.rs:521-557)."""
+    from needle_amd.ivf import IvfConfig, IvfIndex
+
+    rng = np.random.default_rng({"duplicates": 5, "near_ties": 6, "nprobe_ge_nlist": 7, "many_lists": 8}[case])
+    d = 64
+    if case == "many_lists":
+        n, nlist, nprobe = 40000, 1500, 24
+        cents = rng.standard_normal((nlist, d)).astype(F)
+    elif case == "nprobe_ge_nlist":
+        n, nlist, nprobe = 4000, 12, 12
+        cents = rng.standard_normal((nlist, d)).astype(F)
+    else:
+        n, nlist, nprobe = 20000, 96, 8
+        seeds = rng.standard_normal((12, d)).astype(F)
+        cents = np.repeat(seeds, 8, axis=0)  # 12 groups of 8 identical centroids: every boundary falls inside a group
+        if case == "near_ties":
+            cents = cents * (F(1.0) + F(1e-6) * rng.standard_normal(cents.shape).astype(F))
+        cents = np.ascontiguousarray(cents[rng.permutation(nlist)])
+    base = (cents[rng.integers(0, nlist, n)] + F(0.3) * rng.standard_normal((n, d)).astype(F)).astype(F)
+    ix = IvfIndex(d, IvfConfig.new(nlist).with_nprobe(nprobe), ctx=ctx)
+    ix.set_centroids(cents)
+    ix.add(range(n), base)
+    assign = oracle.ivf_assign(base, cents)
+    offsets, order = oracle.ivf_lists_from_assignment(assign, nlist)
+    queries = np.concatenate([cents[:40] + F(0.05) * rng.standard_normal((min(40, nlist), d)).astype(F),
+                              rng.standard_normal((200, d)).astype(F)]).astype(F)
+    probes = ix.probe(queries)
+    for i in range(0, queries.shape[0], 7):
+        assert np.array_equal(probes[i], oracle.ivf_probe(queries[i], cents, nprobe)), i
+    for precision in ("bf16", "fp32"):
+        _check_search(oracle, ix, base, cents, offsets, order, queries, nprobe, 10, precision=precision)
+    ix.close()
