@@ -33,19 +33,25 @@ constexpr uint32_t MERGE_KEYS_MAX = 2048 + KPRIME_MAX;
 // kprime-th largest of keys[0 .. total) (total >= kprime), found bit by bit; all keys are distinct
 // per-lane counts over pairs of keys (a count does not care which lane sees which key), one cross-lane sum per bit
 __device__ inline uint64_t wave_kth_largest_lds(const uint64_t* keys, uint32_t total, uint32_t kprime, uint32_t lane) {
+    constexpr int PER = 12;  // up to 768 keys (the usual gather) are selected from registers
+    if (total <= 64u * PER) {
+        uint64_t r[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) r[u] = ((uint32_t)u * 64u + lane < total) ? keys[u * 64 + lane] : 0ull;
+        return wave_kth_largest_regs64<PER>(r, total, kprime);
+    }
     uint64_t prefix = 0;
     const uint32_t pairs = total / 2;
     const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(keys);  // keys is 16-byte aligned
     for (int bit = 63; bit >= 0; --bit) {
         const uint64_t trial = prefix | (1ull << bit);
-        uint32_t c = 0;
-        for (uint32_t i = lane; i < pairs; i += 64) {
-            const ulonglong2 v = k2[i];
-            c += (v.x >= trial ? 1u : 0u) + (v.y >= trial ? 1u : 0u);
+        uint32_t c = 0;  // wave-uniform
+        for (uint32_t i0 = 0; i0 < pairs; i0 += 64) {
+            const bool in = i0 + lane < pairs;
+            const ulonglong2 v = in ? k2[i0 + lane] : ulonglong2{0ull, 0ull};
+            c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(v.x >= trial)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(v.y >= trial));
         }
-        if ((total & 1u) && lane == 0) c += keys[total - 1] >= trial ? 1u : 0u;
-#pragma unroll
-        for (int off = 32; off; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off);
+        if ((total & 1u) && keys[total - 1] >= trial) c += 1;
         if (c >= kprime) prefix = trial;
     }
     return prefix;
@@ -186,18 +192,36 @@ constexpr int DS_T = (KPRIME_MAX + 63) / 64;
 
 // kprime-th largest of ord[0 .. total) bit by bit (total >= kprime); zeros sort below every live score
 __device__ inline uint32_t wave_kth_largest_u32(const uint32_t* ord, uint32_t total, uint32_t kprime, uint32_t lane) {
-    uint32_t kth = 0;
-    const uint32_t t4 = (total + 3u) / 4u;  // the caller pads the array with zeros up to a multiple of 256 entries
     const uint4* o4 = reinterpret_cast<const uint4*>(ord);
+    const uint32_t t4 = (total + 3u) / 4u;  // the caller pads the array with zeros up to a multiple of 256 entries
+    if (t4 <= 64u * 4u) {  // up to 1024 values: four 16-byte reads per lane, then everything from registers
+        uint32_t r[16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint4 v = ((uint32_t)u * 64u + lane < t4) ? o4[u * 64 + lane] : uint4{0u, 0u, 0u, 0u};
+            r[4 * u] = v.x; r[4 * u + 1] = v.y; r[4 * u + 2] = v.z; r[4 * u + 3] = v.w;
+        }
+        // (register u covers values of the u/4-th block of 256: its ballots are skipped once the block is past the end)
+        uint32_t kth = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t trial = kth | (1u << bit);
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if ((uint32_t)(u / 4) * 256u < total) cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(r[u] >= trial));
+            if (cnt >= kprime) kth = trial;
+        }
+        return kth;
+    }
+    uint32_t kth = 0;
     for (int bit = 31; bit >= 0; --bit) {
         const uint32_t trial = kth | (1u << bit);
-        uint32_t cnt = 0;
-        for (uint32_t i = lane; i < t4; i += 64) {
-            const uint4 v = o4[i];
-            cnt += (v.x >= trial ? 1u : 0u) + (v.y >= trial ? 1u : 0u) + (v.z >= trial ? 1u : 0u) + (v.w >= trial ? 1u : 0u);
+        uint32_t cnt = 0;  // wave-uniform
+        for (uint32_t i0 = 0; i0 < t4; i0 += 64) {
+            const uint4 v = (i0 + lane < t4) ? o4[i0 + lane] : uint4{0u, 0u, 0u, 0u};
+            cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(v.x >= trial)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(v.y >= trial)) +
+                   __builtin_popcountll(__builtin_amdgcn_ballot_w64(v.z >= trial)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(v.w >= trial));
         }
-#pragma unroll
-        for (int off = 32; off; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
         if (cnt >= kprime) kth = trial;
     }
     return kth;

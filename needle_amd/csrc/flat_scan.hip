@@ -275,16 +275,12 @@ __global__ __launch_bounds__(64) void tau_refresh_kernel(const uint2* __restrict
     }
     __syncthreads();
     if (total < kseed || total > MAXE) return;
-    uint32_t prefix = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t trial = prefix | (1u << bit);
-        uint32_t cnt = 0;
-        for (uint32_t i = 0; i < total; i += 64) {
-            const bool ge = (i + lane < total) && (ord[i + lane] >= trial);
-            cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ge));
-        }
-        if (cnt >= kseed) prefix = trial;
-    }
+    // the listed scores go to registers once (f2ord of a score is never 0, the filler); the bit passes then cost a
+    // compare and a ballot count per 64 of them
+    uint32_t r[MAXE / 64];
+#pragma unroll
+    for (uint32_t u = 0; u < MAXE / 64; ++u) r[u] = (u * 64 < total && u * 64 + lane < total) ? ord[u * 64 + lane] : 0u;
+    const uint32_t prefix = wave_kth_largest_regs<MAXE / 64>(r, total, kseed);
     if (lane == 0) {
         // Stay below the kseed-th listed score by a few times the score uncertainty: the rows inside that band
         // are the ones the bound check needs to see listed before it can certify the k-th hit.
@@ -308,7 +304,14 @@ __global__ __launch_bounds__(64) void tau0_kernel(const float* __restrict__ pre_
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
     const float* v = pre_max + (uint64_t)q * groups;
     uint32_t prefix = 0;
-    if (groups >= kprime) {
+    constexpr uint32_t T0_PER = 16;  // up to 1024 group maxima are read once and selected from registers
+    if (groups >= kprime && groups <= 64 * T0_PER) {
+        uint32_t r[T0_PER];
+#pragma unroll
+        for (uint32_t u = 0; u < T0_PER; ++u) r[u] = (u * 64 < groups && u * 64 + lane < groups) ? f2ord(v[u * 64 + lane]) : 0u;
+        // f2ord(-inf) = 0x007fffff > 0: a group with no live row still counts as a value, below every score
+        prefix = wave_kth_largest_regs<T0_PER>(r, groups, kprime);
+    } else if (groups >= kprime) {
         for (int bit = 31; bit >= 0; --bit) {
             const uint32_t trial = prefix | (1u << bit);
             uint32_t cnt = 0;

@@ -66,4 +66,64 @@ __device__ inline float wave_compact_list(uint2* __restrict__ list, uint32_t n_e
     return ord2f((uint32_t)(prefix >> 32));
 }
 
+// The k-th largest of up to 64 * PER 32-bit values held in registers (element u * 64 + lane in v[u]; missing elements
+// are 0 and never counted; total >= k live values, all non-zero).  Every bit costs a compare and a ballot count per 64
+// values: no LDS round trip, no shuffle.
+template <int PER>
+__device__ inline uint32_t wave_kth_largest_regs(const uint32_t (&v)[PER], uint32_t total, uint32_t k) {
+    uint32_t prefix = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t trial = prefix | (1u << bit);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if ((uint32_t)u * 64u < total) cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(v[u] >= trial));
+        if (cnt >= k) prefix = trial;
+    }
+    return prefix;
+}
+
+// The same for distinct 64-bit keys (high word: score ordinal, never 0): the high word of the k-th largest key first,
+// then -- only when several keys share that high word -- its low word among those keys.
+template <int PER>
+__device__ inline uint64_t wave_kth_largest_regs64(const uint64_t (&v)[PER], uint32_t total, uint32_t k) {
+    uint32_t hp = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t trial = hp | (1u << bit);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if ((uint32_t)u * 64u < total) cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64((uint32_t)(v[u] >> 32) >= trial));
+        if (cnt >= k) hp = trial;
+    }
+    uint32_t gt = 0, eq = 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+        if ((uint32_t)u * 64u < total) {
+            gt += __builtin_popcountll(__builtin_amdgcn_ballot_w64((uint32_t)(v[u] >> 32) > hp));
+            eq += __builtin_popcountll(__builtin_amdgcn_ballot_w64((uint32_t)(v[u] >> 32) == hp));
+        }
+    const uint32_t need = k - gt;  // 1 <= need <= eq
+    uint32_t lp = 0;
+    if (eq == 1) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if ((uint32_t)u * 64u < total) {
+                const uint64_t m = __builtin_amdgcn_ballot_w64((uint32_t)(v[u] >> 32) == hp);
+                if (m) lp = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v[u], (int)__builtin_ctzll(m));
+            }
+    } else {
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t trial = lp | (1u << bit);
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int u = 0; u < PER; ++u)
+                if ((uint32_t)u * 64u < total)
+                    cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64((uint32_t)(v[u] >> 32) == hp && (uint32_t)v[u] >= trial));
+            if (cnt >= need) lp = trial;
+        }
+    }
+    return ((uint64_t)hp << 32) | lp;
+}
+
 }  // namespace nh
