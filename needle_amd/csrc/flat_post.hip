@@ -32,31 +32,20 @@ constexpr uint32_t MERGE_KEYS_MAX = 2048 + KPRIME_MAX;
 
 // kprime-th largest of keys[0 .. total) (total >= kprime), found bit by bit; all keys are distinct
 // per-lane counts over pairs of keys (a count does not care which lane sees which key), one cross-lane sum per bit
-__device__ inline uint64_t wave_kth_largest_lds(const uint64_t* keys, uint32_t total, uint32_t kprime, uint32_t lane) {
-    constexpr int PER = 12;  // up to 768 keys (the usual gather) are selected from registers
-    if (total <= 64u * PER) {
-        uint64_t r[PER];
+template <int PER>
+__device__ inline uint64_t kth_largest_lds_regs(const uint64_t* keys, uint32_t total, uint32_t kprime, uint32_t lane) {
+    uint64_t r[PER];
 #pragma unroll
-        for (int u = 0; u < PER; ++u) r[u] = ((uint32_t)u * 64u + lane < total) ? keys[u * 64 + lane] : 0ull;
-        return wave_kth_largest_regs64<PER>(r, total, kprime);
-    }
-    uint64_t prefix = 0;
-    const uint32_t pairs = total / 2;
-    const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(keys);  // keys is 16-byte aligned
-    for (int bit = 63; bit >= 0; --bit) {
-        const uint64_t trial = prefix | (1ull << bit);
-        uint32_t c = 0;  // wave-uniform
-        for (uint32_t i0 = 0; i0 < pairs; i0 += 64) {
-            const bool in = i0 + lane < pairs;
-            const ulonglong2 v = in ? k2[i0 + lane] : ulonglong2{0ull, 0ull};
-            c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(v.x >= trial)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(v.y >= trial));
-        }
-        if ((total & 1u) && keys[total - 1] >= trial) c += 1;
-        if (c >= kprime) prefix = trial;
-    }
-    return prefix;
+    for (int u = 0; u < PER; ++u) r[u] = ((uint32_t)u * 64u < total && (uint32_t)u * 64u + lane < total) ? keys[u * 64 + lane] : 0ull;
+    return wave_kth_largest_regs64<PER>(r, total, kprime);
+}
+// the keys go to registers once: PER per lane (12 cover the usual gather of 768 keys, 36 the largest buffer)
+template <int PER>
+__device__ inline uint64_t wave_kth_largest_lds(const uint64_t* keys, uint32_t total, uint32_t kprime, uint32_t lane) {
+    return kth_largest_lds_regs<PER>(keys, total, kprime, lane);
 }
 
+template <int PER>
 __global__ __launch_bounds__(64) void merge_select_kernel(PostParams p, uint32_t MERGE_KEYS, uint32_t MERGE_FAST_LISTS) {
     extern __shared__ __attribute__((aligned(16))) uint64_t mkeys[];  // [MERGE_KEYS], then loff[MERGE_FAST_LISTS + 1]
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
@@ -113,7 +102,7 @@ __global__ __launch_bounds__(64) void merge_select_kernel(PostParams p, uint32_t
         const uint32_t gtotal = (uint32_t)__shfl((int)incl, 63);
         if (total + gtotal > MERGE_KEYS) {  // wave-uniform; then total > kprime, because gtotal <= MERGE_KEYS - kprime
             __syncthreads();
-            const uint64_t kth = wave_kth_largest_lds(mkeys, total, p.kprime, lane);
+            const uint64_t kth = wave_kth_largest_lds<PER>(mkeys, total, p.kprime, lane);
             uint32_t base = 0;
             for (uint32_t i = 0; i < total; i += 64) {  // in-place: a chunk is read whole before any of its slots is written
                 const uint64_t key = (i + lane < total) ? mkeys[i + lane] : 0ull;
@@ -138,7 +127,7 @@ __global__ __launch_bounds__(64) void merge_select_kernel(PostParams p, uint32_t
     uint64_t prefix = 0;
     float tau = -INFINITY;
     if (total >= p.kprime) {
-        prefix = wave_kth_largest_lds(mkeys, total, p.kprime, lane);
+        prefix = wave_kth_largest_lds<PER>(mkeys, total, p.kprime, lane);
         tau = ord2f((uint32_t)(prefix >> 32));
     }
     uint32_t base = 0;
@@ -172,7 +161,9 @@ hipError_t launch_merge_select(const PostParams& p, hipStream_t stream) {
         if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 2u * KPRIME_MAX && a <= 4096 && b >= 1 && b <= 2048) { keys = a / 2 * 2; fast = b; }
     }
     const size_t lds = (size_t)keys * sizeof(uint64_t) + ((size_t)fast + 1) * sizeof(uint32_t);
-    hipLaunchKernelGGL(merge_select_kernel, dim3(p.q), dim3(64), lds, stream, p, keys, fast);
+    static_assert(MERGE_KEYS_MAX <= 64 * 36, "register image of the merge buffer");
+    if (keys <= 64u * 12u) hipLaunchKernelGGL(merge_select_kernel<12>, dim3(p.q), dim3(64), lds, stream, p, keys, fast);
+    else hipLaunchKernelGGL(merge_select_kernel<36>, dim3(p.q), dim3(64), lds, stream, p, keys, fast);
     return hipGetLastError();
 }
 
