@@ -58,8 +58,10 @@ def search_device(handle, dq, k, *, nprobe=0, precision="fp32", d_filter=None):
 
 
 def timed(fn, steps, warmup):
+    """Seconds per call over `steps` calls.  At least two untimed calls come first: an index adapts the number of candidates
+    it keeps after its first batch (and grows its workspace once more), which belongs to start-up, not to the steady rate."""
     out = None
-    for _ in range(warmup):
+    for _ in range(max(warmup, 2)):
         out = fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
