@@ -73,10 +73,18 @@ __global__ __launch_bounds__(256) void shard_merge_kernel(const unsigned char* _
         if (sid[i] != sid[j]) return sid[i] < sid[j];
         return i < j;
     };
+    // (both passes below read four entries per step, so that their LDS reads are in flight together: a loop that reads
+    // one entry per iteration waits out an LDS latency per entry)
     for (uint32_t j = threadIdx.x; j < cap; j += 256) {
         uint32_t dup = 0;
-        if (!sdead[j])
-            for (uint32_t i = 0; i < cap; ++i) dup |= (!sdead[i] && i != j && sid[i] == sid[j] && before(i, j)) ? 1u : 0u;
+        if (!sdead[j]) {
+            uint32_t i = 0;
+            for (; i + 4 <= cap; i += 4) {
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) dup |= (!sdead[i + u] && i + u != j && sid[i + u] == sid[j] && before(i + u, j)) ? 1u : 0u;
+            }
+            for (; i < cap; ++i) dup |= (!sdead[i] && i != j && sid[i] == sid[j] && before(i, j)) ? 1u : 0u;
+        }
         sdup[j] = dup;
     }
     __syncthreads();
@@ -85,8 +93,12 @@ __global__ __launch_bounds__(256) void shard_merge_kernel(const unsigned char* _
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < cap; j += 256) {
         if (sdead[j]) continue;
-        uint32_t rank = 0;
-        for (uint32_t i = 0; i < cap; ++i) rank += (!sdead[i] && i != j && before(i, j)) ? 1u : 0u;
+        uint32_t rank = 0, i = 0;
+        for (; i + 4 <= cap; i += 4) {
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) rank += (!sdead[i + u] && i + u != j && before(i + u, j)) ? 1u : 0u;
+        }
+        for (; i < cap; ++i) rank += (!sdead[i] && i != j && before(i, j)) ? 1u : 0u;
         atomicAdd(&s_kept, 1u);
         if (rank < k) {
             out_ids[(size_t)q * k + rank] = sid[j];
