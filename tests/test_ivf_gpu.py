@@ -270,7 +270,7 @@ def test_ivf_pq_lists(ctx, oracle, shape):
     ix.close()
 
 
-@pytest.mark.parametrize("case", ["duplicates", "near_ties", "nprobe_ge_nlist", "many_lists"])
+@pytest.mark.parametrize("case", ["duplicates", "near_ties", "nprobe_ge_nlist", "many_lists", "cluster40"])
 def test_probe_set_decided_by_scores(ctx, oracle, case):
     """The search needs the probed lists as a SET: centroids whose first-pass score decides their membership are not
     re-scored, the ones near the nprobe-th are (flat_post.hip, set-only re-score).  Centroid sets that put many
@@ -278,7 +278,7 @@ def test_probe_set_decided_by_scores(ctx, oracle, case):
     probes, and thousands of lists -- must give the oracle's hits all the same (ivf.rs:521-557)."""
     from needle_amd.ivf import IvfConfig, IvfIndex
 
-    rng = np.random.default_rng({"duplicates": 5, "near_ties": 6, "nprobe_ge_nlist": 7, "many_lists": 8}[case])
+    rng = np.random.default_rng({"duplicates": 5, "near_ties": 6, "nprobe_ge_nlist": 7, "many_lists": 8, "cluster40": 9}[case])
     d = 64
     if case == "many_lists":
         n, nlist, nprobe = 40000, 1500, 24
@@ -286,6 +286,12 @@ def test_probe_set_decided_by_scores(ctx, oracle, case):
     elif case == "nprobe_ge_nlist":
         n, nlist, nprobe = 4000, 12, 12
         cents = rng.standard_normal((nlist, d)).astype(F)
+    elif case == "cluster40":
+        # 40 centroids within rounding of each other and 56 far ones: more centroids between the two score margins than
+        # the re-score stages at a time, with the rest of the candidates clearly out
+        n, nlist, nprobe = 20000, 96, 8
+        near = rng.standard_normal((1, d)).astype(F) * (F(1.0) + F(2e-6) * rng.standard_normal((40, d)).astype(F))
+        cents = np.ascontiguousarray(np.concatenate([near, F(4.0) * rng.standard_normal((56, d)).astype(F)])[rng.permutation(nlist)])
     else:
         n, nlist, nprobe = 20000, 96, 8
         seeds = rng.standard_normal((12, d)).astype(F)
