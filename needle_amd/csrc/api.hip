@@ -799,6 +799,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     band.bmax = ix->max_norm;
     band.mnorm = ix->sq_min_norm * (1.0 + 1e-6);
     band.dim = ix->dim; band.metric = ix->metric; band.precision = precision; band.sq8 = sq8 ? 1 : 0;
+    if (const char* e = getenv("NEEDLE_HIP_DEBUG_BAND")) band.width = (float)atof(e);  // development: width of the threshold band
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (seeded) {
         HIP_TRY(ix->w_premax.ensure((size_t)q_pad * 8 * plan.n_splits * sizeof(float)));

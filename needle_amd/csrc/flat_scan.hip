@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64) void tau_refresh_kernel(const uint2* __restrict
         // Stay below the kseed-th listed score by a few times the score uncertainty: the rows inside that band
         // are the ones the bound check needs to see listed before it can certify the k-th hit.
         const double eps = band_eps(band, q);
-        const float t = (float)((double)ord2f(prefix) - 2.0 * eps);
+        const float t = (float)((double)ord2f(prefix) - (double)band.width * eps);
         if (t == t) tau[q] = fmaxf(tau[q], t);
     }
 }
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(64) void tau0_kernel(const float* __restrict__ pre_
             t = ord2f(prefix - 2);
             // as in the refresh between launches: leave the band of scores the bound check must see listed
             if (q < n_queries) {
-                const float tb = (float)((double)t - 2.0 * band_eps(band, q));
+                const float tb = (float)((double)t - (double)band.width * band_eps(band, q));
                 if (tb == tb) t = fminf(t, tb);
             }
         }

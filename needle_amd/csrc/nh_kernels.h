@@ -15,6 +15,7 @@ struct TauBand {
     double bmax, mnorm;  // max row norm; SQ8: |min_vals|
     uint32_t dim;
     int metric, precision, sq8;
+    float width = 2.0f;  // thresholds stay this many score uncertainties below the k-th score they were taken from
 };
 #ifdef __HIPCC__
 // absolute uncertainty of a first-pass score of query q against any row (operand rounding + f32 accumulation)
