@@ -1,21 +1,23 @@
-// bf16 first pass of the exact flat search: v_mfma_f32_32x32x16_bf16, f32 accumulate.
+// bf16 first pass of the exact flat search on the matrix cores, f32 accumulate.  Two kernels share one design:
+// flat_scan_bf16x_kernel (v_mfma_f32_16x16x32_bf16; the one that ships, eight waves of 32 queries per workgroup up to
+// 384 dimensions, four waves beyond) and flat_scan_bf16_kernel (v_mfma_f32_32x32x16_bf16, four waves, one per SIMD;
+// kept as the BF_MF16 = 0 build for comparison).
 //
-// Structure (one workgroup = 4 waves, ONE wave per SIMD, the whole 512-register file per wave):
-//   * the queries are stationary IN REGISTERS: wave w holds the B fragments of its own
-//     32*NT queries for the full dimension (NT * KS fragments of 8 bf16), loaded once;
+// Structure:
+//   * the queries are stationary IN REGISTERS: a wave holds the B fragments of its own queries for the full
+//     dimension, loaded once;
 //   * the rows stream through a ring of LDS slots, one slot = 64 rows x 128 dims (16 KB), filled
 //     by direct-to-LDS loads three stages ahead of the MFMAs.  A wave-instruction of such a load
 //     writes 1 KB linearly (4 rows x 256 B), so the bank-conflict swizzle (16-byte chunk c of row r
 //     lives at chunk c ^ (r & 15)) is applied to the per-lane SOURCE address;
-//   * every wave multiplies ALL 64 staged rows with ITS queries: 2 row tiles x NT query
-//     tiles of 32x32, so one 16-byte LDS fragment feeds NT MFMAs and the rows are fetched
-//     from L2/HBM once per 128*NT queries.  A 128-row tile is walked as two half tiles, which
-//     keeps the accumulators at 32*NT registers beside the 4*NT*KS registers of query fragments.
+//   * every wave multiplies ALL 64 staged rows with ITS queries, so one 16-byte LDS fragment feeds one MFMA per
+//     query tile of the wave and the rows are fetched from L2/HBM once per workgroup (256 or 128 queries).  A 128-row
+//     tile is walked as two half tiles, which keeps the accumulators small beside the query fragments.
 // One barrier per stage; the loads in flight are retired by counted vmcnt waits, never vmcnt(0).
 //
-// Selection: as in the fp32 kernel each lane compares its 16 results per tile with its
-// query's threshold; here every LANE owns its candidate list (query, slice, lane half), so a
-// push is a predicated store and a counter increment with no cross-lane step.
+// Selection: each lane compares its results per tile with its query's threshold; every LANE GROUP sharing a query's
+// column (lane halves in the 32x32 form, lane quarters in the 16x16 form) owns its candidate list (query, slice,
+// group), so a push is a predicated store and a counter increment with no cross-lane step.
 #include "nh_common.h"
 #include "nh_kernels.h"
 #include "nh_scan.h"
