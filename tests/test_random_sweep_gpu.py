@@ -9,6 +9,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+# NEEDLE_TEST_SEED_OFFSET shifts every generator seed: the same sweep over fresh cases (fuzzing runs)
+SEED_OFFSET = int(__import__("os").environ.get("NEEDLE_TEST_SEED_OFFSET", "0"))
+
 F = np.float32
 U64MAX = np.iinfo(np.uint64).max
 METRICS = ["Cosine", "CosineNormalized", "Euclidean", "DotProduct", "Manhattan", "Chebyshev", "Hamming"]
@@ -58,7 +61,7 @@ def _rows(rng, n, dim, kind):
 def test_random_flat_case(ctx, oracle, seed):
     import needle_amd as na
 
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + seed + SEED_OFFSET)
     metric, dim, n, nq, k, precision, kind, splits = _case(rng)
     base, queries = _rows(rng, n, dim, kind), _rows(rng, nq, dim, kind)
     if metric == "CosineNormalized":

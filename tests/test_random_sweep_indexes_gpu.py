@@ -7,6 +7,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+# NEEDLE_TEST_SEED_OFFSET shifts every generator seed: the same sweep over fresh cases (fuzzing runs)
+SEED_OFFSET = int(__import__("os").environ.get("NEEDLE_TEST_SEED_OFFSET", "0"))
+
 F = np.float32
 U64MAX = np.iinfo(np.uint64).max
 
@@ -72,7 +75,7 @@ def test_random_ivf_case(ctx, oracle, seed):
     from needle_amd.ivf import IvfConfig, IvfIndex
     from needle_amd.quantization import ProductQuantizer
 
-    rng = np.random.default_rng(5000 + seed)
+    rng = np.random.default_rng(5000 + seed + SEED_OFFSET)
     use_pq = rng.random() < 0.35
     dim = int(rng.choice([8, 24, 48, 96, 128, 384] if use_pq else [3, 17, 48, 100, 128, 384]))
     n = int(rng.choice([40, 900, 6000, 30000, 90000]))
@@ -128,7 +131,7 @@ def test_random_code_scan_case(ctx, oracle, seed):
     from needle_amd.quantization import (BinaryIndex, BinaryQuantizer, PqIndex, ProductQuantizer, ScalarQuantizer,
                                          Sq8Index)
 
-    rng = np.random.default_rng(7000 + seed)
+    rng = np.random.default_rng(7000 + seed + SEED_OFFSET)
     which = ["sq8", "pq", "binary"][seed % 3]
     n = int(rng.choice([3, 200, 5000, 40000, 120000]))
     nq = int(rng.choice([1, 9, 64, 200]))
