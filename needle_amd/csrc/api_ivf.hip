@@ -219,59 +219,115 @@ __global__ __launch_bounds__(256) void ivf_regroup_count_kernel(RegroupBufs g) {
     if (i >= g.q) return;
     uint32_t at = 0;
     const uint32_t n = min(g.probe_n[i], g.np);
-    for (uint32_t sl = 0; sl < n; ++sl) {
-        const uint32_t l = g.probe[(uint64_t)i * g.np + sl];
-        g.slot_rel[(uint64_t)i * g.np + sl] = at;
-        at += rg_runs(g, l);
-        atomicAdd(&g.cnt[rg_stage(g, sl) * g.nlist + l], 1u);
+    // eight probe slots per step: their list ids, then their list lengths, are fetched together (a slot at a time the
+    // loop is a chain of two dependent loads per slot)
+    for (uint32_t s0 = 0; s0 < n; s0 += 8) {
+        uint32_t l[8], r[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) l[u] = g.probe[(uint64_t)i * g.np + min(s0 + u, n - 1)];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) r[u] = rg_runs(g, l[u]);
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint32_t sl = s0 + u;
+            if (sl < n) {
+                g.slot_rel[(uint64_t)i * g.np + sl] = at;
+                at += r[u];
+                atomicAdd(&g.cnt[rg_stage(g, sl) * g.nlist + l[u]], 1u);
+            }
+        }
     }
     g.qlists[i] = at;
 }
 
-// exclusive sums of value(0 .. n-1) into out[0 .. n] by one workgroup of 1024 threads; returns the total
-template <typename F>
-__device__ uint32_t rg_block_scan(uint32_t n, F value, uint32_t* out, uint32_t* part) {
-    const uint32_t t = threadIdx.x, per = (n + 1023) / 1024;
-    const uint32_t b = min(n, t * per), e = min(n, b + per);
-    uint32_t s = 0;
-    for (uint32_t i = b; i < e; ++i) s += value(i);
-    part[t] = s;
+// three exclusive sums at once by one workgroup of 1024 threads (one set of barriers for all three):
+// value_j(0 .. n_j - 1) into out_j[0 .. n_j]; part holds 3 x 1024 words
+template <typename F0, typename F1, typename F2>
+__device__ void rg_block_scan3(uint32_t n0, F0 v0, uint32_t* out0, uint32_t n1, F1 v1, uint32_t* out1, uint32_t n2, F2 v2,
+                               uint32_t* out2, uint32_t (*part)[1024], uint32_t (&total)[3]) {
+    const uint32_t t = threadIdx.x;
+    const uint32_t n[3] = {n0, n1, n2};
+    uint32_t b[3], e[3], s[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const uint32_t per = (n[j] + 1023) / 1024;
+        b[j] = min(n[j], t * per);
+        e[j] = min(n[j], b[j] + per);
+    }
+    // a thread's values are fetched once, all loads in flight together (up to RG_CACHE per sum: 16K queries, 5461 lists;
+    // beyond that the plain loops run, one dependent load after the other)
+    constexpr uint32_t RG_CACHE = 16;
+    uint32_t c0[RG_CACHE], c1[RG_CACHE], c2[RG_CACHE];
+    const bool cached = e[0] - b[0] <= RG_CACHE && e[1] - b[1] <= RG_CACHE && e[2] - b[2] <= RG_CACHE;  // block-uniform
+    if (cached) {
+#pragma unroll
+        for (uint32_t u = 0; u < RG_CACHE; ++u) {
+            c0[u] = b[0] + u < e[0] ? v0(b[0] + u) : 0u;
+            c1[u] = b[1] + u < e[1] ? v1(b[1] + u) : 0u;
+            c2[u] = b[2] + u < e[2] ? v2(b[2] + u) : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < RG_CACHE; ++u) { s[0] += c0[u]; s[1] += c1[u]; s[2] += c2[u]; }
+    } else {
+        for (uint32_t i = b[0]; i < e[0]; ++i) s[0] += v0(i);
+        for (uint32_t i = b[1]; i < e[1]; ++i) s[1] += v1(i);
+        for (uint32_t i = b[2]; i < e[2]; ++i) s[2] += v2(i);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) part[j][t] = s[j];
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) {
-        const uint32_t v = t >= off ? part[t - off] : 0u;
+        uint32_t v[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v[j] = t >= off ? part[j][t - off] : 0u;
         __syncthreads();
-        part[t] += v;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) part[j][t] += v[j];
         __syncthreads();
     }
-    uint32_t acc = t ? part[t - 1] : 0u;
-    const uint32_t total = part[1023];
-    for (uint32_t i = b; i < e; ++i) {
-        out[i] = acc;
-        acc += value(i);
+    uint32_t acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        acc[j] = t ? part[j][t - 1] : 0u;
+        total[j] = part[j][1023];
     }
-    if (t == 0) out[n] = total;
+    if (cached) {
+#pragma unroll
+        for (uint32_t u = 0; u < RG_CACHE; ++u) {
+            if (b[0] + u < e[0]) { out0[b[0] + u] = acc[0]; acc[0] += c0[u]; }
+            if (b[1] + u < e[1]) { out1[b[1] + u] = acc[1]; acc[1] += c1[u]; }
+            if (b[2] + u < e[2]) { out2[b[2] + u] = acc[2]; acc[2] += c2[u]; }
+        }
+    } else {
+        for (uint32_t i = b[0]; i < e[0]; ++i) { out0[i] = acc[0]; acc[0] += v0(i); }
+        for (uint32_t i = b[1]; i < e[1]; ++i) { out1[i] = acc[1]; acc[1] += v1(i); }
+        for (uint32_t i = b[2]; i < e[2]; ++i) { out2[i] = acc[2]; acc[2] += v2(i); }
+    }
+    if (t == 0) { out0[n0] = total[0]; out1[n1] = total[1]; out2[n2] = total[2]; }
     __syncthreads();
-    return total;
 }
 
 __global__ __launch_bounds__(1024) void ivf_regroup_scan_kernel(RegroupBufs g) {
-    __shared__ uint32_t part[1024];
+    __shared__ uint32_t part[3][1024];
     __shared__ uint32_t most;
     if (threadIdx.x == 0) most = 0;
     __syncthreads();
     const uint32_t SL = 3 * g.nlist;
-    const uint32_t total_lists = rg_block_scan(g.q, [&](uint32_t i) { return g.qlists[i]; }, g.lbase, part);
+    uint32_t total[3];
+    rg_block_scan3(
+        g.q, [&](uint32_t i) { return g.qlists[i]; }, g.lbase,
+        SL, [&](uint32_t i) { return g.cnt[i]; }, g.pair_off,
+        SL, [&](uint32_t i) {
+            const uint32_t l = i % g.nlist, c = g.cnt[i];
+            return (c == 0 || g.list_len[l] == 0) ? 0u : rg_runs(g, l) * ((c + g.item_queries - 1) / g.item_queries);
+        }, g.item_off, part, total);
     for (uint32_t i = threadIdx.x; i <= g.q; i += 1024) g.lbase_dev[i] = g.lbase[i] * g.lpe;
     uint32_t m = 0;
     for (uint32_t i = threadIdx.x; i < g.q; i += 1024) m = max(m, g.qlists[i]);
     atomicMax(&most, m);
-    rg_block_scan(SL, [&](uint32_t i) { return g.cnt[i]; }, g.pair_off, part);
-    rg_block_scan(SL, [&](uint32_t i) {
-        const uint32_t l = i % g.nlist, c = g.cnt[i];
-        return (c == 0 || g.list_len[l] == 0) ? 0u : rg_runs(g, l) * ((c + g.item_queries - 1) / g.item_queries);
-    }, g.item_off, part);
+    __syncthreads();
     if (threadIdx.x == 0) {
-        g.totals[0] = total_lists;
+        g.totals[0] = total[0];
         g.totals[1] = g.item_off[g.nlist];
         g.totals[2] = g.item_off[2 * g.nlist];
         g.totals[3] = g.item_off[SL];
