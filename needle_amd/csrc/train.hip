@@ -252,6 +252,8 @@ static needle_hip_status ivf_train_impl(needle_hip_ctx* c, const float* vectors,
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
+constexpr uint32_t PQ_LDS_DSUB = 64;  // widest sub-vector whose 256-entry codebook is staged in LDS (64 KB)
+
 __device__ __forceinline__ float pq_l2sq(const float* __restrict__ a, const float* __restrict__ b, uint32_t n) {
     float s = -0.0f;
     for (uint32_t i = 0; i < n; ++i) { const float d = a[i] - b[i]; const float p = d * d; s = s + p; }
@@ -263,11 +265,15 @@ template <int DSUB>  // 0: any width (the sub-vector is re-read through the cach
 __global__ __launch_bounds__(256) void pq_encode_kernel(const float* __restrict__ v, uint32_t n, uint32_t dim, uint32_t dsub_rt,
                                                         const float* __restrict__ codebooks, const uint32_t* __restrict__ ncent,
                                                         uint32_t m, uint8_t* __restrict__ out) {
-    extern __shared__ float cb[];  // [256][dsub]
+    extern __shared__ float cb_lds[];  // [256][dsub] when it fits (sub-vectors of up to PQ_LDS_DSUB dimensions)
     const uint32_t s = blockIdx.y, dsub = DSUB ? DSUB : dsub_rt;
     const uint32_t k = ncent ? min(ncent[s], 256u) : 256u;
-    for (uint32_t i = threadIdx.x; i < 256 * dsub; i += 256) cb[i] = codebooks[(uint64_t)s * 256 * dsub + i];
-    __syncthreads();
+    const float* cb = codebooks + (uint64_t)s * 256 * dsub;  // wider codebooks are read through the cache
+    if (dsub <= PQ_LDS_DSUB) {  // block-uniform
+        for (uint32_t i = threadIdx.x; i < 256 * dsub; i += 256) cb_lds[i] = cb[i];
+        __syncthreads();
+        cb = cb_lds;
+    }
     const uint32_t row = blockIdx.x * 256 + threadIdx.x;
     if (row >= n) return;
     const float* sub = v + (uint64_t)row * dim + s * dsub;
@@ -305,9 +311,13 @@ __global__ __launch_bounds__(256) void pq_seed_distance_kernel(const float* __re
 __global__ __launch_bounds__(256) void pq_assign_kernel(const float* __restrict__ v, uint32_t n, uint32_t dim, uint32_t off,
                                                         uint32_t dsub, const float* __restrict__ cent, uint32_t k,
                                                         uint32_t* __restrict__ assign) {
-    extern __shared__ float cb[];
-    for (uint32_t i = threadIdx.x; i < k * dsub; i += 256) cb[i] = cent[i];
-    __syncthreads();
+    extern __shared__ float cb_lds[];
+    const float* cb = cent;
+    if (dsub <= PQ_LDS_DSUB) {  // block-uniform
+        for (uint32_t i = threadIdx.x; i < k * dsub; i += 256) cb_lds[i] = cent[i];
+        __syncthreads();
+        cb = cb_lds;
+    }
     const uint32_t row = blockIdx.x * 256 + threadIdx.x;
     if (row >= n) return;
     const float* sub = v + (uint64_t)row * dim + off;
@@ -410,7 +420,7 @@ needle_hip_status pq_train_impl(needle_hip_ctx* c, const float* vectors, uint64_
         std::fill(assign.begin(), assign.end(), 0u);
         for (uint32_t it = 0; it < iterations; ++it) {
             HIP_TRY(hipMemcpyAsync(d_cent, cent.data(), (size_t)k * dsub * sizeof(float), hipMemcpyHostToDevice, c->stream));
-            hipLaunchKernelGGL(pq_assign_kernel, dim3((nn + 255) / 256), dim3(256), (size_t)k * dsub * sizeof(float), c->stream, d_v, nn,
+            hipLaunchKernelGGL(pq_assign_kernel, dim3((nn + 255) / 256), dim3(256), dsub <= PQ_LDS_DSUB ? (size_t)k * dsub * sizeof(float) : 0, c->stream, d_v, nn,
                                dim, off, dsub, d_cent, k, d_assign);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(fresh.data(), d_assign, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -446,7 +456,7 @@ hipError_t nh::launch_pq_encode(const float* d_v, uint32_t n, uint32_t dim, uint
                             uint8_t* d_out, hipStream_t stream) {
     const uint32_t dsub = dim / m;
     const dim3 grid((n + 255) / 256, m), block(256);
-    const size_t lds = (size_t)256 * dsub * sizeof(float);
+    const size_t lds = dsub <= PQ_LDS_DSUB ? (size_t)256 * dsub * sizeof(float) : 0;
     switch (dsub) {
     case 4: hipLaunchKernelGGL(pq_encode_kernel<4>, grid, block, lds, stream, d_v, n, dim, dsub, d_books, d_ncent, m, d_out); break;
     case 8: hipLaunchKernelGGL(pq_encode_kernel<8>, grid, block, lds, stream, d_v, n, dim, dsub, d_books, d_ncent, m, d_out); break;
@@ -462,7 +472,6 @@ extern "C" needle_hip_status needle_hip_pq_train(needle_hip_ctx* c, const float*
     if (n == 0 || !vectors) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "Empty training data");
     if (dim == 0 || m == 0 || dim % m != 0)
         return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "dim (%u) must be divisible by the subvector count (%u)", dim, m);
-    if (dim / m > 64) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "sub-vectors of %u dimensions do not fit the on-chip codebook", dim / m);
     if (n > 0x7fffffffull) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "too many training rows");
     try {
         return pq_train_impl(c, vectors, n, dim, m, iterations, seed, out_codebooks, out_ncent);
@@ -478,7 +487,6 @@ extern "C" needle_hip_status needle_hip_pq_encode(needle_hip_ctx* c, const float
     if (!codebooks || !vectors || !out_codes) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (dim == 0 || m == 0 || dim % m != 0)
         return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "dim (%u) must be divisible by the subvector count (%u)", dim, m);
-    if (dim / m > 64) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "sub-vectors of %u dimensions do not fit the on-chip codebook", dim / m);
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     const uint64_t B = 1u << 20;  // rows per upload

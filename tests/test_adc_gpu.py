@@ -190,7 +190,7 @@ def test_binary_masks_ties_and_edges(ctx, oracle):
     small.close()
 
 
-@pytest.mark.parametrize("shape", [(3000, 32, 4), (5000, 96, 12), (200, 24, 3), (1500, 30, 2)])
+@pytest.mark.parametrize("shape", [(3000, 32, 4), (5000, 96, 12), (200, 24, 3), (1500, 30, 2), (1200, 384, 2), (900, 200, 2)])
 def test_pq_training_and_encoding_on_the_device(ctx, oracle, shape):
     """needle_hip_pq_train / needle_hip_pq_encode against the oracle's seeded restatement of
     ProductQuantizer::{train, encode} (quantization.rs:330-446, kmeans :597-711): same draws -> bit-equal

@@ -96,8 +96,6 @@ def test_random_ivf_case(ctx, oracle, seed):
     m = 0
     if use_pq:
         m = int(rng.choice([d for d in (2, 4, 8, 12) if dim % d == 0]))
-        if dim // m > 64:  # the device encoder keeps a sub-space's codebook on chip: NEEDLE_HIP_ERR_UNSUPPORTED beyond 64 dimensions
-            pytest.skip("sub-vectors wider than 64 dimensions")
         opq = oracle.ProductQuantizer.train(base[: min(n, 1500)], m, seed=seed)
         codes = opq.encode(base)
         cfg = cfg.with_pq(m)
