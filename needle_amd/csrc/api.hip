@@ -1083,15 +1083,6 @@ extern "C" needle_hip_status needle_hip_batch_search(needle_hip_index* ix, const
         return fail(NEEDLE_HIP_ERR_DIMENSION_MISMATCH, "Dimension mismatch: expected %u, got %u", ix->dim, query_dim);
     if (q > 0 && (!queries || !out_counts || (params->k > 0 && (!out_ids || !out_dists))))
         return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null query or output pointer");
-    for (uint32_t i = 0; i < q; ++i) {
-        const float* v = queries + (size_t)i * query_dim;
-        for (uint32_t j = 0; j < query_dim; ++j) {
-            if (std::isnan(v[j]))
-                return fail(NEEDLE_HIP_ERR_INVALID_VECTOR, "Invalid vector: Vector contains NaN at index %u (query %u)", j, i);
-            if (std::isinf(v[j]))
-                return fail(NEEDLE_HIP_ERR_INVALID_VECTOR, "Invalid vector: Vector contains Inf at index %u (query %u)", j, i);
-        }
-    }
     if (q == 0) return NEEDLE_HIP_OK;
     SlotLease lease(ix, params);
     ST_TRY(lease.status());
@@ -1112,6 +1103,25 @@ extern "C" needle_hip_status needle_hip_batch_search(needle_hip_index* ix, const
     off += (size_t)q * kk * sizeof(float);
     uint32_t* d_c = (uint32_t*)(base + off);
     HIP_TRY(hipMemcpyAsync(d_q, queries, (size_t)q * ix->dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    {
+        // NaN / Inf in ANY query fails the whole batch before any search.  The uploaded copy is checked on the device (the
+        // first offending query); the host then reads only that query to word the error as the reference does.
+        HIP_TRY(ix->w_flagcnt.ensure(sizeof(uint32_t)));
+        HIP_TRY(launch_validate_rows(d_q, q, ix->dim, ix->w_flagcnt.as<uint32_t>(), c->stream));
+        uint32_t bad = 0xffffffffu;
+        HIP_TRY(hipMemcpyAsync(&bad, ix->w_flagcnt.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (bad != 0xffffffffu && bad < q) {
+            const float* v = queries + (size_t)bad * query_dim;
+            for (uint32_t j = 0; j < query_dim; ++j) {
+                if (std::isnan(v[j]))
+                    return fail(NEEDLE_HIP_ERR_INVALID_VECTOR, "Invalid vector: Vector contains NaN at index %u (query %u)", j, bad);
+                if (std::isinf(v[j]))
+                    return fail(NEEDLE_HIP_ERR_INVALID_VECTOR, "Invalid vector: Vector contains Inf at index %u (query %u)", j, bad);
+            }
+            return fail(NEEDLE_HIP_ERR_INVALID_VECTOR, "Invalid vector: Vector contains NaN or Inf (query %u)", bad);
+        }
+    }
     const uint32_t* d_filter = nullptr;
     if (params->filter_bitmask && ix->n > 0) {
         const size_t words = (ix->n + 31) / 32;
