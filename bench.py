@@ -14,7 +14,8 @@ arithmetic whatever the first pass; the fp32 first pass is timed beside it).  Th
 IVF nlist 4096 / nprobe 32 over 1.25M x 384, SQ8 and PQ m=48 over 6.25M x 384), each with its own roofline
 object, parity sample and host-pointer rate, and the reference's HNSW restated on the CPU over a bounded sample.
 
---gpus N > 1 (launched by torch.distributed.run, one rank per GPU): the base -- by default 10M x 384 --
+--gpus N > 1 (one rank per GPU: under torch.distributed.run, or started by this script itself when no launcher set
+WORLD_SIZE -- never a silent single-GPU run): the base -- by default 10M x 384 --
 is split into N contiguous row blocks, every GPU scans its block for ALL queries, the per-shard results
 travel in one RCCL all-gather and are merged on every rank (needle_hip_sharded_batch_search_device):
 strong scaling of one batch.  `--shard queries` is the opt-in alternative (every GPU holds the whole base
@@ -66,6 +67,8 @@ def parse(argv=None):
     ap.add_argument("--paths", default=DEFAULT_PATHS, help="N = 1: other configurations folded into the line ('none' = skip)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per first-pass launch from a separate rocprofv3 --pmc run")
+    ap.add_argument("--backend", default="hip",
+                    help="'hip' (the product wiring) or module:Class of a stand-in with HipBackend's interface (CPU tests)")
     return ap.parse_args(argv)
 
 
@@ -457,7 +460,8 @@ def run(args, be):
             if line is not None:
                 line["paths"] = [{"path": "ivf_sharded", "error": f"not finished within {args.ivf_leg_seconds:.0f} s"}]
                 print(json.dumps(line), flush=True)
-            os._exit(0 if line is None or parity_ok(line) else 3)
+            # a stalled collective leg is a failed run: the flat line is out, the exit status says so (3 = parity, 4 = stall)
+            os._exit(4 if line is None or parity_ok(line) else 3)
 
         dog = threading.Timer(args.ivf_leg_seconds, bail)
         dog.daemon = True
@@ -483,18 +487,87 @@ def parity_ok(line):
     return True
 
 
+def visible_gpus():
+    """GPUs this process could use, counted without initialising the runtime (the launcher must stay GPU-free)."""
+    try:
+        return int(torch.cuda.device_count())
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+def launch_ranks(args, argv):
+    """`bench.py --gpus N` started without a launcher: start the N ranks ourselves, one process per GPU, with the
+    environment torch.distributed.run would give them, relay their output and fail when any of them fails.  Runs before
+    anything in this process touches a GPU; the children are ordinary child processes (never an exec)."""
+    import socket
+    import subprocess
+
+    n = args.gpus
+    transport = os.environ.get("NEEDLE_BENCH_BACKEND", "nccl")
+    if args.backend == "hip":
+        have = visible_gpus()
+        if have == 0 or (transport == "nccl" and have < n):
+            print(f"bench.py: --gpus {n} needs {n} visible GPUs for the RCCL exchange, found {have} "
+                  f"(NEEDLE_BENCH_BACKEND=gloo rehearses the control flow with ranks sharing devices)", file=sys.stderr)
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-u", os.path.abspath(__file__)] + list(argv if argv is not None else sys.argv[1:])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(cmd, env=env))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} ended with status {code}; stopping the other ranks", file=sys.stderr)
+                for o in alive:  # exactly the processes started above
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def make_backend(spec, rank, local_rank, world):
+    if spec == "hip":
+        return HipBackend(rank, local_rank, world)
+    import importlib
+
+    mod, _, attr = spec.partition(":")
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("gloo")  # stand-in backends exchange over host tensors
+    return getattr(importlib.import_module(mod), attr)(rank, local_rank, world)
+
+
 def main(argv=None, backend=None):
     args = parse(argv)
+    if backend is None and "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, argv)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
+        if world == 1:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE=1: refusing to report one rank as {args.gpus} GPUs",
+                  file=sys.stderr)
+            return 2
         args.gpus = world
-    be = backend(rank, local_rank, world) if backend is not None else HipBackend(rank, local_rank, world)
+    be = backend(rank, local_rank, world) if backend is not None else make_backend(args.backend, rank, local_rank, world)
     try:
         line = run(args, be)
     finally:
         be.close()
+        if args.backend != "hip" and dist.is_initialized():
+            dist.destroy_process_group()
     if line is not None:
         print(json.dumps(line), flush=True)
         if not parity_ok(line):

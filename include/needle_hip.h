@@ -469,10 +469,16 @@ int needle_hip_comm_world(const needle_hip_comm* comm);
  * sort by distance, truncate) and merge_shard_results, src/persistence/shard.rs:
  * 622-643: needle_hip_batch_search_device on this rank's shard, local ids turned
  * global by adding row_offset, ONE all-gather of the ranks' (ids | distances |
- * counts) over RCCL / xGMI, and a merge by (distance, global id) on every rank;
- * all on the context's stream, no host step in between.  Collective: every rank
- * calls it with the same q, k and queries; every rank receives the full result.
- * world * k <= 2048.  Device pointers. */
+ * counts) over RCCL / xGMI, and a merge by (distance, global id) on every rank.
+ * The local search runs on one of the shard's search slots (its own stream) and
+ * is complete when the exchange is enqueued on the context's stream; the call
+ * returns with the merged result in place.  Collective: every rank calls it with
+ * the same q, k and queries; every rank receives the full result.  A rank whose
+ * local search fails still joins the all-gather with a marked slot, so the other
+ * ranks do not wait for it: it returns its own error, the others
+ * NEEDLE_HIP_ERR_RCCL naming the failed ranks.  world * k <= 2048.  Device
+ * pointers; the queries must be complete before the call (the library does not
+ * order itself behind the caller's streams). */
 needle_hip_status needle_hip_sharded_batch_search_device(needle_hip_index* shard, needle_hip_comm* comm,
                                                          uint64_t row_offset, const float* d_queries,
                                                          uint32_t q, const needle_search_params* params,
@@ -489,8 +495,9 @@ needle_hip_status needle_hip_merge_shard_slots_device(needle_hip_ctx* ctx, const
                                                       float* d_out_dists, uint32_t* d_out_counts);
 
 /* needle_hip_batch_top_k_device for callers that cannot allocate device memory
- * (code under HIP graph capture, tight serving loops, harnesses that forbid
- * hipMalloc).  It has no counterpart in the reference.  Same arguments and
+ * (tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart
+ * in the reference.  The call synchronises the library's stream before it
+ * returns, so it cannot itself be recorded under HIP graph capture.  Same arguments and
  * results; the workspace (histograms, per-workgroup tie counts, the selected keys)
  * lives in a 1 MiB array that is part of the library's code object, one copy per
  * GPU for the life of the process, so the call issues no hipMalloc / hipFree.

@@ -19,6 +19,8 @@ Hit = Tuple[int, float]
 
 
 class GpuAccelerator:
+    MERGE_ENTRIES = 3750  # (distance, id) entries of one query that needle_hip_merge_topk_device merges per call
+
     def __init__(self, device: int = 0, ctx: Context | None = None):
         self.ctx = ctx or Context(device)
 
@@ -76,22 +78,37 @@ class GpuAccelerator:
         q = _f32(query).reshape(1, -1)
         starts = list(range(0, n, chunk_size))
         kk = max(k, 1)
-        ids = np.full((len(starts), 1, kk), np.iinfo(np.uint64).max, dtype=np.uint64)
-        dists = np.full((len(starts), 1, kk), np.inf, dtype=np.float32)
-        counts = np.zeros((len(starts), 1), dtype=np.uint32)
+        # the device merge takes MERGE_ENTRIES (distance, id) entries of one query per call: the chunks' lists are folded
+        # into a running top k, a group at a time (top-k merging is associative, so the grouping does not change the
+        # result); a k too large for even two lists per call is served by one resident search, which returns the same
+        group = self.MERGE_ENTRIES // kk - 1
+        if group < 1:
+            return self.fused_search(query, b, k, distance_type)
         metric = DistanceType(distance_type).metric()
-        for c, s in enumerate(starts):
-            ix = FlatIndex(self.ctx, b[s:s + chunk_size], metric, arith=_lib.ARITH_ACCEL_CHUNK4)
-            try:
-                ci, cd, cc = ix.search(q, min(k, min(chunk_size, n - s)))
-            finally:
-                ix.close()
-            m = int(cc[0])
-            ids[c, 0, :m] = ci[0, :m] + np.uint64(s)
-            dists[c, 0, :m] = cd[0, :m]
-            counts[c, 0] = m
-        oi, od, oc = self.ctx.merge_topk(dists, ids, counts, k)
-        return [(int(oi[0, j]), float(od[0, j])) for j in range(int(oc[0]))]
+        umax = np.iinfo(np.uint64).max
+        run_i = np.full((1, 1, kk), umax, dtype=np.uint64)
+        run_d = np.full((1, 1, kk), np.inf, dtype=np.float32)
+        run_c = np.zeros((1, 1), dtype=np.uint32)
+        for g0 in range(0, len(starts), group):
+            part = starts[g0:g0 + group]
+            ids = np.full((len(part), 1, kk), umax, dtype=np.uint64)
+            dists = np.full((len(part), 1, kk), np.inf, dtype=np.float32)
+            counts = np.zeros((len(part), 1), dtype=np.uint32)
+            for c, s in enumerate(part):
+                ix = FlatIndex(self.ctx, b[s:s + chunk_size], metric, arith=_lib.ARITH_ACCEL_CHUNK4)
+                try:
+                    ci, cd, cc = ix.search(q, min(k, min(chunk_size, n - s)))
+                finally:
+                    ix.close()
+                m = int(cc[0])
+                ids[c, 0, :m] = ci[0, :m] + np.uint64(s)
+                dists[c, 0, :m] = cd[0, :m]
+                counts[c, 0] = m
+            oi, od, oc = self.ctx.merge_topk(np.concatenate([run_d, dists]), np.concatenate([run_i, ids]),
+                                             np.concatenate([run_c, counts]), k)
+            m = int(oc[0])
+            run_i[0, 0, :m], run_d[0, 0, :m], run_c[0, 0] = oi[0, :m], od[0, :m], m
+        return [(int(run_i[0, 0, j]), float(run_d[0, 0, j])) for j in range(int(run_c[0, 0]))]
 
     # -- streaming_multi_query_search, gpu/mod.rs:906-951 ----------------------
     def streaming_multi_query_search(self, queries, vectors, k: int, distance_type: DistanceType) -> List[List[Hit]]:

@@ -81,7 +81,7 @@ extern "C" needle_hip_status needle_hip_flat_build_prefix(needle_hip_index* full
         return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "the prefix index is built from a flat index holding its rows");
     if (dims == 0 || dims > full->dim) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "prefix of %u dimensions of %u", dims, full->dim);
     needle_hip_ctx* c = full->ctx;
-    std::lock_guard<std::mutex> g(full->mu);
+    std::lock_guard g(full->mu);
     HIP_TRY(hipSetDevice(c->device));
     DevMem mem;
     float* d_tmp = nullptr;
@@ -164,7 +164,7 @@ extern "C" needle_hip_status needle_hip_adaptive_search(needle_hip_index* full, 
     ST_TRY(needle_hip_batch_search_device(coarse, d_qt, q, &sp, d_cids, d_cd, d_cn));
     // phase 2: re-rank over all dimensions
     {
-        std::lock_guard<std::mutex> g(full->mu);
+        std::lock_guard g(full->mu);
         hipLaunchKernelGGL(ad_rerank_kernel, dim3(q), dim3(256), 0, c->stream, d_q, full->d_raw, full->dim, d_cids, d_cd, d_cn, coarse_k,
                            k, d_oids, d_od, d_oc, d_on);
         HIP_TRY(hipGetLastError());

@@ -72,14 +72,14 @@ static void handle_retire(T* h) {
 needle_hip_index* nh::index_new() {
     needle_hip_index* ix = handle_alloc<needle_hip_index>();
     if (ix) {
-        std::lock_guard<std::mutex> g(g_reg_mu);
+        std::lock_guard g(g_reg_mu);
         g_live_indexes.insert(ix);
     }
     return ix;
 }
 
 static void register_context(needle_hip_ctx* c) {
-    std::lock_guard<std::mutex> g(g_reg_mu);
+    std::lock_guard g(g_reg_mu);
     g_live_contexts.insert(c);
 }
 
@@ -118,7 +118,7 @@ extern "C" void needle_hip_shutdown(needle_hip_ctx* c) {
     if (!c) return;
     std::vector<needle_hip_index*> bound;
     {
-        std::lock_guard<std::mutex> g(g_reg_mu);
+        std::lock_guard g(g_reg_mu);
         if (!g_live_contexts.erase(c)) return;
         for (const void* p : g_live_indexes)
             if (((const needle_hip_index*)p)->ctx == c) bound.push_back((needle_hip_index*)p);
@@ -135,21 +135,21 @@ extern "C" void needle_hip_shutdown(needle_hip_ctx* c) {
 
 extern "C" needle_hip_status needle_hip_set_profiling(needle_hip_ctx* c, int on) {
     if (!c) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "ctx is null");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard g(c->mu);
     c->profiling = on != 0;
     return NEEDLE_HIP_OK;
 }
 
 extern "C" needle_hip_status needle_hip_get_metrics(needle_hip_ctx* c, needle_hip_metrics* out) {
     if (!c || !out) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard g(c->mu);
     *out = c->m;
     return NEEDLE_HIP_OK;
 }
 
 extern "C" needle_hip_status needle_hip_reset_metrics(needle_hip_ctx* c) {
     if (!c) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "ctx is null");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard g(c->mu);
     c->m = needle_hip_metrics{};
     return NEEDLE_HIP_OK;
 }
@@ -163,7 +163,7 @@ static void release_workspace(needle_hip_index* ix);
 void nh::index_free(needle_hip_index* ix) {
     if (!ix) return;
     {
-        std::lock_guard<std::mutex> g(g_reg_mu);
+        std::lock_guard g(g_reg_mu);
         if (!g_live_indexes.erase(ix)) return;
     }
     (void)hipSetDevice(ix->ctx->device);
@@ -279,7 +279,7 @@ nh::SlotLease::SlotLease(needle_hip_index* parent, const needle_search_params* p
         slot_->busy = true;
     }
     // operand copies a view must not build for itself, then the view of the parent's data
-    std::lock_guard<std::mutex> g(parent->mu);
+    std::lock_guard g(parent->mu);
     if (st_ == NEEDLE_HIP_OK && search_uses_bf16_copy(parent, params)) st_ = ensure_bf16_copy(parent);
     if (st_ == NEEDLE_HIP_OK && parent->kind == KIND_IVF && parent->centroids && parent->centroids->n > 0 &&
         flat_scan_bf16_dpad(parent->dim) != 0)
@@ -300,14 +300,14 @@ nh::SlotLease::~SlotLease() {
     if (!slot_) return;
     if (getenv("NEEDLE_HIP_DEBUG_TRACE")) fprintf(stderr, "[needle_hip] index %p: slot %p released\n", (void*)parent_, (void*)slot_);
     {
-        std::lock_guard<std::mutex> g(parent_->mu);  // what the search learned about the index
+        std::lock_guard g(parent_->mu);  // what the search learned about the index
         parent_->bf16_extra_slack = std::max(parent_->bf16_extra_slack, slot_->ix.bf16_extra_slack);
         if (parent_->centroids) parent_->centroids->bf16_extra_slack = std::max(parent_->centroids->bf16_extra_slack, slot_->cent.bf16_extra_slack);
     }
     {
         needle_hip_ctx* pc = parent_->ctx;
         const needle_hip_metrics& d = slot_->ctx.m;
-        std::lock_guard<std::mutex> g(pc->mu);
+        std::lock_guard g(pc->mu);
         pc->m.searches += d.searches; pc->m.queries += d.queries; pc->m.fallback_queries += d.fallback_queries;
         pc->m.scan_launches += d.scan_launches; pc->m.scan_ms_total += d.scan_ms_total;
         pc->m.refined_queries += d.refined_queries; pc->m.binary_code_scans += d.binary_code_scans;
@@ -316,7 +316,7 @@ nh::SlotLease::~SlotLease() {
         if (d.searches && slot_->ctx.profiling) pc->m.last_search_ms = d.last_search_ms;
     }
     {
-        std::lock_guard<std::mutex> lk(parent_->pool_mu);
+        std::lock_guard lk(parent_->pool_mu);
         slot_->busy = false;
     }
     parent_->pool_cv.notify_one();
@@ -520,7 +520,7 @@ extern "C" needle_hip_status needle_hip_flat_build_device(needle_hip_ctx* c, con
 
 extern "C" needle_hip_status needle_hip_index_set_valid_mask(needle_hip_index* ix, const uint32_t* valid_bitmask) {
     if (!ix) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "index is null");
-    std::lock_guard<std::mutex> g(ix->mu);
+    std::lock_guard g(ix->mu);
     HIP_TRY(hipSetDevice(ix->ctx->device));
     return upload_mask(ix, valid_bitmask);
 }
@@ -693,7 +693,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     if (exact_only) {
         ST_TRY(run_exact(ix, d_queries, nullptr, q, k, d_filter, d_out_ids, d_out_dists, d_out_counts));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard g(c->mu);
         c->m.fallback_queries += q;
         return NEEDLE_HIP_OK;
     }
@@ -941,7 +941,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     if (c->profiling) {
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard g(c->mu);
         c->m.scan_launches += 1;
         c->m.scan_ms_total += ms;
         c->m.last_scan_ms = ms;
@@ -971,7 +971,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
             HIP_TRY(launch_scatter_results(ix->r_idx.as<uint32_t>(), n_flagged, k, ix->r_ids.as<uint64_t>(), ix->r_dists.as<float>(),
                                            ix->r_cnt.as<uint32_t>(), d_out_ids, d_out_dists, d_out_counts, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            std::lock_guard<std::mutex> g(c->mu);
+            std::lock_guard g(c->mu);
             c->m.fallback_queries += n_flagged;
             return NEEDLE_HIP_OK;
         }
@@ -992,13 +992,13 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
                                            ix->r_dists.as<float>(), ix->r_cnt.as<uint32_t>(), d_out_ids, d_out_dists,
                                            d_out_counts, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            std::lock_guard<std::mutex> g(c->mu);
+            std::lock_guard g(c->mu);
             c->m.refined_queries += n_flagged;
             return NEEDLE_HIP_OK;
         }
         ST_TRY(run_exact(ix, d_queries, pp.flagged, n_flagged, k, d_filter, d_out_ids, d_out_dists, d_out_counts));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard g(c->mu);
         c->m.fallback_queries += n_flagged;
     }
     return NEEDLE_HIP_OK;
@@ -1053,10 +1053,10 @@ static needle_hip_status search_device_locked(needle_hip_index* ix, const float*
         HIP_TRY(hipEventSynchronize(c->ev[3]));
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard g(c->mu);
         c->m.last_search_ms = ms;
     }
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard g(c->mu);
     c->m.searches += 1;
     c->m.queries += q;
     return NEEDLE_HIP_OK;
@@ -1151,7 +1151,7 @@ extern "C" needle_hip_status needle_hip_batch_distance(needle_hip_ctx* c, needle
         return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "batch distance covers cosine, euclidean and dot product");
     if (n == 0) return NEEDLE_HIP_OK;  // vectors.is_empty() -> Ok(vec![]), gpu/mod.rs:315-317
     if (!query || !base || !out || dim == 0) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(c->scratch[0].ensure((size_t)dim * sizeof(float)));
     HIP_TRY(c->scratch[1].ensure((size_t)n * dim * sizeof(float)));
@@ -1210,7 +1210,7 @@ extern "C" needle_hip_status needle_hip_merge_topk_device(needle_hip_ctx* c, con
     if (!d_counts || !d_out_counts || lists == 0) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if ((uint64_t)lists * per * 16ull > 60000ull)
         return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "merge of %u x %u entries per query exceeds the on-chip budget", lists, per);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     if (k == 0 || per == 0) {
         HIP_TRY(launch_fill_empty(d_out_ids, d_out_dists, d_out_counts, q, k, c->stream));

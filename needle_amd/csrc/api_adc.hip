@@ -53,7 +53,7 @@ needle_hip_status nh::pq_search_batch_device(needle_hip_index* ix, const float* 
     if (k > KPRIME_MAX) {  // beyond the per-list budget of the table scan: every row scored in the table's arithmetic
         ST_TRY(run_exact(ix, d_queries, nullptr, q, k, d_filter, d_out_ids, d_out_dists, d_out_counts));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard g(c->mu);
         c->m.fallback_queries += q;
         return NEEDLE_HIP_OK;
     }
@@ -122,7 +122,7 @@ needle_hip_status nh::pq_search_batch_device(needle_hip_index* ix, const float* 
         if (c->profiling) {
             float ms = 0.0f;
             HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-            std::lock_guard<std::mutex> g(c->mu);
+            std::lock_guard g(c->mu);
             c->m.scan_launches += 1;
             c->m.scan_ms_total += ms;
             c->m.last_scan_ms = ms;

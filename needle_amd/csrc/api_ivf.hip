@@ -519,7 +519,7 @@ static needle_hip_status ivf_probe_device(needle_hip_index* ix, const float* d_q
     HIP_TRY(ix->v_probe_n.ensure((size_t)q * sizeof(uint32_t)));
     HIP_TRY(ix->v_probe32.ensure((size_t)q * np * sizeof(uint32_t)));
     {
-        std::lock_guard<std::mutex> g(ix->centroids->mu);
+        std::lock_guard g(ix->centroids->mu);
         // bf16 first pass over the centroids: the probe lists it returns are the exact ones all the same
         // (an fp32 first pass over a few thousand centroids measured slower: 5.3 against 3.9 ms per 10K-query batch)
         ST_TRY(flat_search_batch_device(ix->centroids, d_queries, q, np, NEEDLE_PRECISION_BF16, nullptr,
@@ -542,7 +542,7 @@ extern "C" needle_hip_status needle_hip_ivf_probe(needle_hip_index* ix, const fl
     if (q == 0) return NEEDLE_HIP_OK;
     if (!queries || !out_list_ids || !out_counts) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (nprobe == 0) { memset(out_counts, 0, sizeof(uint32_t) * q); return NEEDLE_HIP_OK; }
-    std::lock_guard<std::mutex> g(ix->mu);
+    std::lock_guard g(ix->mu);
     needle_hip_ctx* c = ix->ctx;
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t np = std::min(nprobe, ix->nlist);
@@ -587,7 +587,7 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     if (exact_only) {
         ST_TRY(run_exact(ix, d_queries, nullptr, q, k, d_filter, d_out_ids, d_out_dists, d_out_counts, d_probe, d_probe_n, np));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard g(c->mu);
         c->m.fallback_queries += q;
         return NEEDLE_HIP_OK;
     }
@@ -780,7 +780,7 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     if (c->profiling) {
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard g(c->mu);
         c->m.list_scans += 1;  // (the probe's own first pass over the centroids is counted under scan_launches)
         c->m.list_scan_ms_total += ms;
     }
@@ -789,7 +789,7 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
         ST_TRY(run_exact(ix, d_queries, pp.flagged, n_flagged, k, d_filter, d_out_ids, d_out_dists, d_out_counts, d_probe,
                          d_probe_n, np));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard g(c->mu);
         c->m.fallback_queries += n_flagged;
     }
     return NEEDLE_HIP_OK;

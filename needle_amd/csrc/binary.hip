@@ -313,7 +313,7 @@ extern "C" needle_hip_status needle_hip_binary_quantize(needle_hip_ctx* c, const
     if (n == 0) return NEEDLE_HIP_OK;
     if (dim == 0 || !thresholds || !vectors || !out_codes) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (n > 0x7fffffffull) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "too many rows in one call");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t W = (dim + 63) / 64, nbytes = (dim + 7) / 8;
     HIP_TRY(c->scratch[0].ensure((size_t)n * dim * sizeof(float)));
@@ -400,13 +400,13 @@ needle_hip_status nh::binary_search_batch_device(needle_hip_index* ix, const flo
     if (c->profiling) {
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard g(c->mu);
         c->m.scan_launches += 1;
         c->m.scan_ms_total += ms;
         c->m.last_scan_ms = ms;
     }
     {
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard g(c->mu);
         c->m.binary_code_scans += single_scan ? 2 : 3;
     }
     return NEEDLE_HIP_OK;

@@ -76,7 +76,7 @@ struct needle_hip_ctx {
     bool profiling = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     needle_hip_metrics m{};
-    std::mutex mu;
+    std::recursive_mutex mu;  // recursive: a host-pointer operator holds it across staging, its _device form and the copy back
     std::mutex prof_mu;  // held by a whole search while profiling is on (the events ev[] are shared by the context's indexes)
     nh::DevBuf scratch[8];  // operator-level calls
     void* topk_static = nullptr;   // device address of the static top-k workspace on this context's device (ops.hip)

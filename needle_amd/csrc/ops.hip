@@ -78,7 +78,7 @@ extern "C" needle_hip_status needle_hip_normalize_device(needle_hip_ctx* c, need
     if (n == 0 || dim == 0) return NEEDLE_HIP_OK;
     if (!d_vectors) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "vectors is null");
     if ((n + NZ_ROWS - 1) / NZ_ROWS > 0x7fffffffull) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "too many vectors");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     hipLaunchKernelGGL(normalize_rows_kernel, dim3((uint32_t)((n + NZ_ROWS - 1) / NZ_ROWS)), dim3(NZ_ROWS), 0, c->stream, d_vectors,
                        n, dim, (int)arith);
@@ -93,16 +93,18 @@ extern "C" needle_hip_status needle_hip_normalize(needle_hip_ctx* c, needle_arit
     ST_TRY(check_arith(arith));
     if (n == 0 || dim == 0) return NEEDLE_HIP_OK;
     if (!vectors) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "vectors is null");
+    // one lock for staging, the device form and the copy back: the staging buffer is shared by the context's callers
+    std::lock_guard whole(c->mu);
     float* d = nullptr;
     {
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard g(c->mu);
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(c->scratch[1].ensure((size_t)n * dim * sizeof(float)));
         d = c->scratch[1].as<float>();
         HIP_TRY(hipMemcpyAsync(d, vectors, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
     }
     ST_TRY(needle_hip_normalize_device(c, arith, d, n, dim));
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard g(c->mu);
     HIP_TRY(hipMemcpyAsync(vectors, d, (size_t)n * dim * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return NEEDLE_HIP_OK;
@@ -311,7 +313,7 @@ extern "C" needle_hip_status needle_hip_batch_top_k_device(needle_hip_ctx* c, co
                                                            uint32_t* d_out_counts) {
     ST_TRY(topk_check_args(c, d_scores, rows, n, k, d_out_idx, d_out_scores, d_out_counts));
     if (rows == 0) return NEEDLE_HIP_OK;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     if (k == 0 || n == 0) {
         HIP_TRY(launch_fill_empty(d_out_idx, d_out_scores, d_out_counts, rows, k, c->stream));
@@ -325,8 +327,8 @@ extern "C" needle_hip_status needle_hip_batch_top_k_device(needle_hip_ctx* c, co
     return NEEDLE_HIP_OK;
 }
 
-// The same operator for callers that cannot allocate (code under HIP graph capture, serving loops, harnesses
-// that forbid hipMalloc): its workspace is this file-scope array, one copy per GPU, held until the process ends.
+// The same operator for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc; the
+// call synchronises its stream, so it is not for use under graph capture): its workspace is this file-scope array, one copy per GPU, held until the process ends.
 // The name below is a host-side stand-in; the device address is taken once per context by
 // topk_static_setup (called from needle_hip_init with the context's device current) and only that pointer is
 // ever handed to kernels and memsets.
@@ -354,7 +356,7 @@ extern "C" needle_hip_status needle_hip_batch_top_k_device_noalloc(needle_hip_ct
                     "top-k of %u rows x %llu scores at k = %u needs %zu bytes of workspace; the allocation-free entry point "
                     "holds %zu (use needle_hip_batch_top_k_device, or fewer rows per call)",
                     rows, (unsigned long long)n, k, bytes, c->topk_static_bytes);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     if (bytes == 0) {
         HIP_TRY(launch_fill_empty(d_out_idx, d_out_scores, d_out_counts, rows, k, c->stream));
@@ -374,9 +376,11 @@ extern "C" needle_hip_status needle_hip_batch_top_k(needle_hip_ctx* c, const flo
     if (rows == 0) return NEEDLE_HIP_OK;
     const size_t kk = k ? k : 1;
     const size_t in_bytes = ((size_t)rows * n * sizeof(float) + 15) & ~(size_t)15;
+    // one lock for staging, the device form and the copy back: the staging buffer is shared by the context's callers
+    std::lock_guard whole(c->mu);
     unsigned char* d = nullptr;
     {
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard g(c->mu);
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(c->scratch[2].ensure(in_bytes + (size_t)rows * kk * 12 + (size_t)rows * 4 + 64));
         d = c->scratch[2].as<unsigned char>();
@@ -386,7 +390,7 @@ extern "C" needle_hip_status needle_hip_batch_top_k(needle_hip_ctx* c, const flo
     float* d_sc = (float*)(d + in_bytes + (size_t)rows * kk * 8);
     uint32_t* d_cnt = (uint32_t*)(d + in_bytes + (size_t)rows * kk * 12);
     ST_TRY(needle_hip_batch_top_k_device(c, (const float*)d, rows, n, k, d_idx, d_sc, d_cnt));
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard g(c->mu);
     if (k > 0) {
         HIP_TRY(hipMemcpyAsync(out_idx, d_idx, (size_t)rows * k * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(out_scores, d_sc, (size_t)rows * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -421,7 +425,7 @@ extern "C" needle_hip_status needle_hip_distance_matrix_device(needle_hip_ctx* c
     ST_TRY(matrix_check_args(c, metric, arith, q, n, dim));
     if (q == 0 || n == 0) return NEEDLE_HIP_OK;  // an empty matrix
     if (!d_queries || !d_base || !d_out) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(launch_distance_matrix(d_queries, q, d_base, n, dim, (int)metric, (int)arith, d_out, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -435,9 +439,11 @@ extern "C" needle_hip_status needle_hip_distance_matrix(needle_hip_ctx* c, needl
     if (q == 0 || n == 0) return NEEDLE_HIP_OK;
     if (!queries || !base || !out) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
     const size_t qf = (size_t)q * dim, bf = (size_t)n * dim, of = (size_t)q * n;
+    // one lock for staging, the device form and the copy back: the staging buffer is shared by the context's callers
+    std::lock_guard whole(c->mu);
     float* d = nullptr;
     {
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard g(c->mu);
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(c->scratch[4].ensure((qf + bf + of) * sizeof(float)));
         d = c->scratch[4].as<float>();
@@ -445,7 +451,7 @@ extern "C" needle_hip_status needle_hip_distance_matrix(needle_hip_ctx* c, needl
         HIP_TRY(hipMemcpyAsync(d + qf, base, bf * sizeof(float), hipMemcpyHostToDevice, c->stream));
     }
     ST_TRY(needle_hip_distance_matrix_device(c, metric, arith, d, q, d + qf, n, dim, d + qf + bf));
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard g(c->mu);
     HIP_TRY(hipMemcpyAsync(out, d + qf + bf, of * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return NEEDLE_HIP_OK;
@@ -461,7 +467,7 @@ extern "C" needle_hip_status needle_hip_multi_query_search_device(needle_hip_ctx
         return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (k > (uint32_t)K_MAX) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "k = %u exceeds %d", k, K_MAX);
     if (n > 0xffffffffull) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "at most 2^32-1 vectors");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     if (k == 0 || n == 0) {
         HIP_TRY(launch_fill_empty(d_out_idx, d_out_dists, d_out_counts, q, k, c->stream));
@@ -496,9 +502,11 @@ extern "C" needle_hip_status needle_hip_multi_query_search(needle_hip_ctx* c, ne
         return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
     const size_t kk = k ? k : 1;
     const size_t qb = ((size_t)q * dim * sizeof(float) + 15) & ~(size_t)15, bb = ((size_t)n * dim * sizeof(float) + 15) & ~(size_t)15;
+    // one lock for staging, the device form and the copy back: the staging buffer is shared by the context's callers
+    std::lock_guard whole(c->mu);
     unsigned char* d = nullptr;
     {
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard g(c->mu);
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(c->scratch[4].ensure(qb + bb + (size_t)q * kk * 12 + (size_t)q * 4 + 64));
         d = c->scratch[4].as<unsigned char>();
@@ -512,7 +520,7 @@ extern "C" needle_hip_status needle_hip_multi_query_search(needle_hip_ctx* c, ne
     uint32_t* d_cnt = (uint32_t*)(d + qb + bb + (size_t)q * kk * 12);
     ST_TRY(needle_hip_multi_query_search_device(c, metric, arith, (const float*)d, q, (const float*)(d + qb), n, dim, k, d_idx, d_ds,
                                                 d_cnt));
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard g(c->mu);
     if (k > 0) {
         HIP_TRY(hipMemcpyAsync(out_idx, d_idx, (size_t)q * k * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(out_dists, d_ds, (size_t)q * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -534,9 +542,11 @@ extern "C" needle_hip_status needle_hip_merge_topk(needle_hip_ctx* c, const floa
         return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
     const size_t kk = k ? k : 1, pp = per ? per : 1;
     const size_t n_in = (size_t)lists * q * pp;
+    // one lock for staging, the device form and the copy back: the staging buffer is shared by the context's callers
+    std::lock_guard whole(c->mu);
     unsigned char* d = nullptr;
     {
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard g(c->mu);
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(c->scratch[2].ensure(n_in * 12 + (size_t)lists * q * 4 + (size_t)q * kk * 12 + (size_t)q * 4 + 64));
         d = c->scratch[2].as<unsigned char>();
@@ -548,7 +558,7 @@ extern "C" needle_hip_status needle_hip_merge_topk(needle_hip_ctx* c, const floa
     uint32_t* d_c = (uint32_t*)(d_od + (size_t)q * kk);
     uint32_t* d_oc = d_c + (size_t)lists * q;
     {
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard g(c->mu);
         if (per > 0) {
             HIP_TRY(hipMemcpyAsync(d_ids, ids, n_in * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipMemcpyAsync(d_d, dists, n_in * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -556,7 +566,7 @@ extern "C" needle_hip_status needle_hip_merge_topk(needle_hip_ctx* c, const floa
         HIP_TRY(hipMemcpyAsync(d_c, counts, (size_t)lists * q * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     }
     ST_TRY(needle_hip_merge_topk_device(c, d_d, d_ids, d_c, lists, q, per, k, d_oi, d_od, d_oc));
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard g(c->mu);
     if (k > 0) {
         HIP_TRY(hipMemcpyAsync(out_ids, d_oi, (size_t)q * k * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(out_dists, d_od, (size_t)q * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));

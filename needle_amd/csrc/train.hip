@@ -487,7 +487,7 @@ extern "C" needle_hip_status needle_hip_pq_encode(needle_hip_ctx* c, const float
     if (!codebooks || !vectors || !out_codes) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (dim == 0 || m == 0 || dim % m != 0)
         return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "dim (%u) must be divisible by the subvector count (%u)", dim, m);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     const uint64_t B = 1u << 20;  // rows per upload
     const uint32_t dsub = dim / m;

@@ -122,12 +122,13 @@ class RcclShardedSearcher:
 
     def search(self, queries: torch.Tensor, k: int):
         from . import _lib
-        from .index import PRECISION
+        from .index import PRECISION, _wait_for_producer
 
         q = queries.shape[0]
         ids = torch.empty((q, max(k, 1)), dtype=torch.int64, device=queries.device)
         dists = torch.empty((q, max(k, 1)), dtype=torch.float32, device=queries.device)
         counts = torch.empty((q,), dtype=torch.int32, device=queries.device)
+        _wait_for_producer(queries)  # the library runs on its own streams: the queries must be complete
         sp = _lib.SearchParams(k=k, nprobe=self.nprobe, precision=PRECISION[self.precision], reserved=0, filter_bitmask=None)
         _lib.check(_lib.lib().needle_hip_sharded_batch_search_device(self.handle, self.comm._h, self.row_offset,
                                                                      queries.data_ptr(), q, C.byref(sp), ids.data_ptr(),
@@ -145,14 +146,14 @@ def hip_local_search_handle(handle, nprobe: int = 0, precision: str = "fp32") ->
     every inverted list / of the code matrix, with centroids, codebooks and quantizer parameters replicated, so the
     probe lists are the same on every rank and the union of the shards' candidates is the whole index's."""
     from . import _lib
-    from .index import PRECISION
+    from .index import PRECISION, _wait_for_producer
 
     def run(queries: torch.Tensor, k: int):
         q = queries.shape[0]
         ids = torch.empty((q, max(k, 1)), dtype=torch.int64, device=queries.device)
         dists = torch.empty((q, max(k, 1)), dtype=torch.float32, device=queries.device)
         counts = torch.empty((q,), dtype=torch.int32, device=queries.device)
-        torch.cuda.current_stream(queries.device).synchronize()  # the library runs on its own stream
+        _wait_for_producer(queries)  # the library runs on its own stream
         sp = _lib.SearchParams(k=k, nprobe=nprobe, precision=PRECISION[precision], reserved=0, filter_bitmask=None)
         _lib.check(_lib.lib().needle_hip_batch_search_device(handle, queries.data_ptr(), q, C.byref(sp), ids.data_ptr(),
                                                              dists.data_ptr(), counts.data_ptr()))

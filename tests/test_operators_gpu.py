@@ -81,6 +81,12 @@ def test_streaming_and_prefiltered_search(accel, oracle):
         si, sd = oracle.accel_streaming_search(q, base, 9, oracle.ACCEL_EUCLIDEAN, chunk)
         got = accel.streaming_batch_search(q, base, 9, DistanceType.Euclidean, chunk_size=chunk)
         assert [h[0] for h in got] == si.tolist() and np.array_equal(_bits([h[1] for h in got]), _bits(sd))
+    # many chunks (more (distance, id) entries than one device merge takes: folded into a running top k), and a k for
+    # which even two lists exceed one merge (served by one resident search): the same hits as the unchunked search
+    for kq, chunk in ((10, 8), (400, 500), (2000, 2500)):
+        si, sd = oracle.accel_fused_search(q, base, kq, oracle.ACCEL_EUCLIDEAN)
+        got = accel.streaming_batch_search(q, base, kq, DistanceType.Euclidean, chunk_size=chunk)
+        assert [h[0] for h in got] == si.tolist() and np.array_equal(_bits([h[1] for h in got]), _bits(sd)), (kq, chunk)
     # prefiltered: (original index, vector) pairs, predicate on the original index (gpu/mod.rs:1033-1080)
     pairs = [(1000 + 3 * i, base[i]) for i in range(2000)]
     keep = lambda idx: idx % 2 == 0  # noqa: E731

@@ -238,3 +238,32 @@ def test_bench_defaults():
     assert "10_000_000 if by_rows else 1_000_000" in src  # N > 1: the 10M base of the metric, split by rows
     assert not bench.parity_ok({"parity": {"ids_equal": False, "dists_bit_equal": True}})
     assert bench.parity_ok({"parity": None, "paths": [{"parity": {"ids_equal": True, "queries_checked": 0}}]})
+
+
+def test_bench_starts_its_own_ranks(capfd, monkeypatch, oracle):
+    """`python bench.py --gpus 2` with no launcher around it: the script starts two ranks itself (child processes with the
+    launcher's environment), rank 0's line says n_gpus 2, and a failing rank fails the run."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(key, raising=False)
+    monkeypatch.setenv("PYTHONPATH", os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), os.environ.get("PYTHONPATH", "")]))
+    argv = ["--gpus", "2", "--rows", "15000", "--dim", "24", "--queries", "12", "--k", "5", "--steps", "1", "--warmup", "0",
+            "--secondary-steps", "0", "--parity-queries", "12", "--backend", "test_sharded_gloo:_CpuBackend"]
+    capfd.readouterr()
+    assert bench.main(argv) == 0
+    out = capfd.readouterr().out
+    lines = [json.loads(ln) for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out  # rank 0 only
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["config"]["sharding"] == "row-blocks x2, all-gather + merge"
+    assert line["parity"]["ids_equal"] and line["parity"]["dists_bit_equal"]
+    # a rank that cannot start ends the whole run with a non-zero status
+    assert bench.main(argv[:-1] + ["test_sharded_gloo:_NoSuchBackend"]) != 0
+    # the product wiring without enough GPUs refuses instead of reporting one rank as two
+    if torch.cuda.device_count() < 2:
+        assert bench.main(["--gpus", "2"]) == 2
+    # one rank told to call itself two GPUs refuses as well
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    assert bench.main(["--gpus", "2", "--backend", "test_sharded_gloo:_CpuBackend"]) == 2

@@ -96,6 +96,33 @@ def test_two_sq8_shards_equal_the_whole_index(ctx, oracle):
         ix.close()
 
 
+@pytest.mark.parametrize("k", [10, 100])
+def test_eight_flat_shards_equal_the_whole_index(ctx, oracle, k):
+    """The 8-way merge of the full node: eight row blocks of one base searched separately (k = 10: the one-wave-per-query
+    form of the merge kernel, 80 entries; k = 100: the workgroup-per-query form, 800 entries), merged == the whole."""
+    import needle_amd as na
+    from needle_amd.sharded import hip_local_search, shard_bounds
+
+    rng = np.random.default_rng(23)
+    n, d = 40_003, 48
+    base = rng.standard_normal((n, d)).astype(F)
+    base[n - 1] = base[17]          # the same row in the first and in the last block: tie broken by global id
+    base[3 * (n // 8) + 5] = base[17]
+    queries = rng.standard_normal((203, d)).astype(F)  # not a multiple of the four queries a workgroup merges
+    queries[0] = base[17]
+    want = oracle.flat_batch_search(queries, base, k, oracle.COSINE)
+    shards, runs, offs = [], [], []
+    for rank in range(8):
+        lo, hi = shard_bounds(n, 8, rank)
+        ix = na.FlatIndex(ctx, base[lo:hi], na.DistanceFunction.Cosine)
+        shards.append(ix)
+        runs.append(hip_local_search(ix, "bf16"))
+        offs.append(lo)
+    _check(_merged(ctx, runs, offs, queries, k), want)
+    for ix in shards:
+        ix.close()
+
+
 def test_rccl_entry_point_world_of_one(ctx, oracle):
     """needle_hip_sharded_batch_search_device with a one-rank RCCL communicator: local search, id offset, the (trivial)
     all-gather and the merge kernel all run; the result is the shard's own, ids shifted by row_offset."""
