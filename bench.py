@@ -97,6 +97,8 @@ class HipBackend:
 
         self.na = na
         self.ctx = na.Context(dev_index)
+        # A/B sweeps of the harness (tools/ab.sh): planning overrides handed to needle_hip_set_tuning, e.g. "stages=15:30"
+        self.ctx.apply_tuning_spec(os.environ.get("NEEDLE_BENCH_TUNE"))
         self.comm = None
         self.comm_error = None
 

@@ -98,6 +98,7 @@ extern "C" {
     pub fn needle_hip_set_profiling(ctx: *mut needle_hip_ctx, on: c_int) -> c_int;
     pub fn needle_hip_get_metrics(ctx: *mut needle_hip_ctx, out: *mut needle_hip_metrics) -> c_int;
     pub fn needle_hip_reset_metrics(ctx: *mut needle_hip_ctx) -> c_int;
+    pub fn needle_hip_set_tuning(ctx: *mut needle_hip_ctx, key: *const c_char, value: f64) -> c_int;
     pub fn needle_hip_metric_from_str(name: *const c_char) -> c_int;
     pub fn needle_hip_flat_build(ctx: *mut needle_hip_ctx, base: *const f32, n: u64, dim: u32, metric: c_int, arith: c_int, valid_bitmask: *const u32, out: *mut *mut needle_hip_index) -> c_int;
     pub fn needle_hip_flat_build_rows(ctx: *mut needle_hip_ctx, rows: *const *const f32, n: u64, dim: u32, metric: c_int, arith: c_int, valid_bitmask: *const u32, out: *mut *mut needle_hip_index) -> c_int;

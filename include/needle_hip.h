@@ -151,6 +151,19 @@ needle_hip_status needle_hip_set_profiling(needle_hip_ctx* ctx, int on);
 needle_hip_status needle_hip_get_metrics(needle_hip_ctx* ctx, needle_hip_metrics* out);
 needle_hip_status needle_hip_reset_metrics(needle_hip_ctx* ctx);
 
+/* Planning overrides for the searches run through this context; no counterpart
+ * in the reference (its GpuConfig, src/experimental/gpu/common.rs:143-175, holds
+ * the analogous knobs).  The library reads no environment variable: tests use
+ * this call to force a code path, the A/B tools to sweep a parameter.  Overrides
+ * move plans and cost, never results.  Keys: "splits", "pre_tiles", "kseed",
+ * "band", "stage0".."stage3" (percent of a slice per staged launch),
+ * "no_dense", "no_set_only", "merge_keys", "merge_lists", "rs_cap", "rs_dc",
+ * "ivf_no_seed", "ivf_seed_rows", "binary_two_scans", "debug" (bit 3: print what
+ * the first pass listed), "trace" and "poison" (process-wide), "reset" (back to
+ * the built-in choices).  Unknown keys fail with
+ * NEEDLE_HIP_ERR_INVALID_ARGUMENT. */
+needle_hip_status needle_hip_set_tuning(needle_hip_ctx* ctx, const char* key, double value);
+
 /* FromStr for DistanceFunction, src/distance.rs:132-145; -1 if unknown. */
 int needle_hip_metric_from_str(const char* name);
 

@@ -24,7 +24,7 @@ ARITH_DISTANCE_RS, ARITH_ACCEL_CHUNK4, ARITH_SERVICE = range(3)
 #: every symbol include/needle_hip.h declares
 EXPORTS = (
     "needle_hip_init", "needle_hip_shutdown", "needle_hip_last_error", "needle_hip_version",
-    "needle_hip_set_profiling", "needle_hip_get_metrics", "needle_hip_reset_metrics", "needle_hip_metric_from_str",
+    "needle_hip_set_profiling", "needle_hip_get_metrics", "needle_hip_reset_metrics", "needle_hip_set_tuning", "needle_hip_metric_from_str",
     "needle_hip_flat_build", "needle_hip_flat_build_rows", "needle_hip_flat_build_device", "needle_hip_flat_build_half",
     "needle_hip_index_set_valid_mask", "needle_hip_index_destroy", "needle_hip_index_len",
     "needle_hip_index_dimensions", "needle_hip_batch_search", "needle_hip_batch_search_device",
@@ -117,6 +117,8 @@ def lib() -> C.CDLL:
     L.needle_hip_get_metrics.argtypes = [vp, C.POINTER(Metrics)]
     L.needle_hip_reset_metrics.restype = i32
     L.needle_hip_reset_metrics.argtypes = [vp]
+    L.needle_hip_set_tuning.restype = i32
+    L.needle_hip_set_tuning.argtypes = [vp, C.c_char_p, C.c_double]
     L.needle_hip_metric_from_str.restype = i32
     L.needle_hip_metric_from_str.argtypes = [C.c_char_p]
     L.needle_hip_flat_build.restype = i32

@@ -147,6 +147,38 @@ extern "C" needle_hip_status needle_hip_get_metrics(needle_hip_ctx* c, needle_hi
     return NEEDLE_HIP_OK;
 }
 
+extern "C" needle_hip_status needle_hip_set_tuning(needle_hip_ctx* c, const char* key, double value) {
+    if (!c || !key) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (!(value >= 0.0) || value > 4.0e9) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "tuning value out of range");
+    std::lock_guard g(c->mu);
+    Tuning& t = c->tune;
+    const uint32_t u = (uint32_t)value;
+    const std::string k = key;
+    if (k == "reset") t = Tuning{};
+    else if (k == "debug") t.debug = u;
+    else if (k == "splits") t.splits = u;
+    else if (k == "pre_tiles") t.pre_tiles = (int32_t)u;
+    else if (k == "kseed") t.kseed = u;
+    else if (k == "band") t.band = (float)value;
+    else if (k == "stage0" || k == "stage1" || k == "stage2" || k == "stage3") {
+        const uint32_t i = (uint32_t)(k[5] - '0');
+        if (u == 0) t.n_stage_pct = std::min(t.n_stage_pct, i);  // stageN = 0 ends the schedule before launch N
+        else { t.stage_pct[i] = u; t.n_stage_pct = std::max(t.n_stage_pct, i + 1); }
+    } else if (k == "no_dense") t.no_dense = u;
+    else if (k == "no_set_only") t.no_set_only = u;
+    else if (k == "merge_keys") t.merge_keys = u;
+    else if (k == "merge_lists") t.merge_lists = u;
+    else if (k == "rs_cap") t.rs_cap = u;
+    else if (k == "rs_dc") t.rs_dc = u;
+    else if (k == "ivf_no_seed") t.ivf_no_seed = u;
+    else if (k == "ivf_seed_rows") t.ivf_seed_rows = u;
+    else if (k == "binary_two_scans") t.binary_two_scans = u;
+    else if (k == "trace") g_trace = u != 0;
+    else if (k == "poison") g_poison = u != 0;
+    else return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "unknown tuning key '%s'", key);
+    return NEEDLE_HIP_OK;
+}
+
 extern "C" needle_hip_status needle_hip_reset_metrics(needle_hip_ctx* c) {
     if (!c) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "ctx is null");
     std::lock_guard g(c->mu);
@@ -285,8 +317,9 @@ nh::SlotLease::SlotLease(needle_hip_index* parent, const needle_search_params* p
         flat_scan_bf16_dpad(parent->dim) != 0)
         st_ = ensure_bf16_copy(parent->centroids);  // the probe step always scores the centroids in bf16
     slot_->ctx.profiling = parent->ctx->profiling;
+    slot_->ctx.tune = parent->ctx->tune;
     slot_->ctx.m = needle_hip_metrics{};
-    if (getenv("NEEDLE_HIP_DEBUG_TRACE"))
+    if (g_trace)
         fprintf(stderr, "[needle_hip] index %p: search takes slot %p (%s), stream %p\n", (void*)parent, (void*)slot_,
                 first ? "new" : "reused", (void*)slot_->ctx.stream);
     sync_view(&slot_->ix, parent, &slot_->ctx, first);
@@ -298,7 +331,7 @@ nh::SlotLease::SlotLease(needle_hip_index* parent, const needle_search_params* p
 
 nh::SlotLease::~SlotLease() {
     if (!slot_) return;
-    if (getenv("NEEDLE_HIP_DEBUG_TRACE")) fprintf(stderr, "[needle_hip] index %p: slot %p released\n", (void*)parent_, (void*)slot_);
+    if (g_trace) fprintf(stderr, "[needle_hip] index %p: slot %p released\n", (void*)parent_, (void*)slot_);
     {
         std::lock_guard g(parent_->mu);  // what the search learned about the index
         parent_->bf16_extra_slack = std::max(parent_->bf16_extra_slack, slot_->ix.bf16_extra_slack);
@@ -710,8 +743,9 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     // few hundred entries in all); beyond that it falls back to gathering in groups
     const uint32_t max_splits = std::max<uint32_t>(1, 1024u / lists_per_split);
     SplitPlan plan = plan_splits(q_tiles, n_tiles, (uint32_t)c->n_cu * (uint32_t)flat_scan_blocks_per_cu(precision), max_splits);
-    if (const char* ds = getenv("NEEDLE_HIP_DEBUG_SPLITS")) {  // development override, applied before any sizing
-        const uint32_t s = (uint32_t)atoi(ds);
+    const Tuning& tune = c->tune;
+    if (tune.splits) {  // tuning override, applied before any sizing
+        const uint32_t s = tune.splits;
         if (s >= 1 && s <= n_tiles && s <= 256 && s <= max_splits) {
             plan.tiles_per_split = (n_tiles + s - 1) / s;
             plan.n_splits = (n_tiles + plan.tiles_per_split - 1) / plan.tiles_per_split;
@@ -722,7 +756,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     // Small bases (the centroid set of an IVF index, k-means assignment): with few rows per query the candidate
     // lists would hold a large part of the base.  The scan then writes the whole score matrix and a selection
     // kernel takes the kprime best of every row.
-    const bool dense = bf16 && ix->n_pad <= DENSE_MAX_ROWS && !(getenv("NEEDLE_HIP_DEBUG_NODENSE"));
+    const bool dense = bf16 && ix->n_pad <= DENSE_MAX_ROWS && !tune.no_dense;
     const uint32_t n_lists = dense ? 1 : plan.n_splits * lists_per_split;  // per query
     if (dense) HIP_TRY(ix->w_scores.ensure((size_t)q_pad * ix->n_pad * sizeof(float)));
 
@@ -781,7 +815,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     sp.kprime = kprime;
     sp.cap = cap;
     sp.xcd_map = plan.xcd_map;
-    if (const char* dbg = getenv("NEEDLE_HIP_DEBUG")) sp.debug = (uint32_t)atoi(dbg);
+    sp.debug = tune.debug;
     // threshold seeding: worth it once a slice is much longer than the sample
     // The seeded threshold is the kseed-th largest sampled group maximum: at least kseed >= k live rows
     // exceed it, and the higher it ranks the fewer rows the main pass lists (rank k against k + 6: 3 % of the
@@ -791,8 +825,8 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     // is, and what the loose threshold lets through is paid again by the merge and the re-score (1M x 768, 10 % filter,
     // k = 100: 2.02 -> 1.86 ms per 1K queries; 24 tiles no better)
     uint32_t pre_tiles = std::min<uint32_t>(sp.kseed > 48 ? 16 : 8, plan.tiles_per_split / 8);
-    if (const char* e = getenv("NEEDLE_HIP_DEBUG_PRE")) pre_tiles = std::min<uint32_t>((uint32_t)atoi(e), plan.tiles_per_split);
-    if (const char* e = getenv("NEEDLE_HIP_DEBUG_KSEED")) sp.kseed = std::min<uint32_t>(std::max<uint32_t>((uint32_t)atoi(e), std::min(k, n)), kprime);
+    if (tune.pre_tiles >= 0) pre_tiles = std::min<uint32_t>((uint32_t)tune.pre_tiles, plan.tiles_per_split);
+    if (tune.kseed) sp.kseed = std::min<uint32_t>(std::max<uint32_t>(tune.kseed, std::min(k, n)), kprime);
     const bool seeded = pre_tiles >= 1 && !(sp.debug & 2u) && !dense;
     TauBand band{};
     band.qn2 = ix->w_qn2.as<double>();
@@ -802,7 +836,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     band.bmax = ix->max_norm;
     band.mnorm = ix->sq_min_norm * (1.0 + 1e-6);
     band.dim = ix->dim; band.metric = ix->metric; band.precision = precision; band.sq8 = sq8 ? 1 : 0;
-    if (const char* e = getenv("NEEDLE_HIP_DEBUG_BAND")) band.width = (float)atof(e);  // development: width of the threshold band
+    if (tune.band > 0.0f) band.width = tune.band;
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (seeded) {
         HIP_TRY(ix->w_premax.ensure((size_t)q_pad * 8 * plan.n_splits * sizeof(float)));
@@ -824,13 +858,11 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
         stages[0] = std::max<uint32_t>(3 * pre_tiles, plan.tiles_per_split / 10);
         stages[1] = plan.tiles_per_split / 4;
         stages[2] = plan.tiles_per_split - stages[0] - stages[1];
-        if (const char* e = getenv("NEEDLE_HIP_DEBUG_STAGES")) {  // development: percentages of a slice per launch, the last takes the rest
-            unsigned pc[4] = {0, 0, 0, 0};
-            const int got = sscanf(e, "%u,%u,%u,%u", &pc[0], &pc[1], &pc[2], &pc[3]);
+        if (tune.n_stage_pct) {  // tuning: percentages of a slice per launch, the last takes the rest
             uint32_t used = 0;
             int r = 0;
-            for (; r < got && r < MAX_STAGES - 1; ++r) {
-                stages[r] = std::min<uint32_t>(std::max<uint32_t>(1, plan.tiles_per_split * pc[r] / 100), plan.tiles_per_split - used - 1);
+            for (; r < (int)tune.n_stage_pct && r < MAX_STAGES - 1; ++r) {
+                stages[r] = std::min<uint32_t>(std::max<uint32_t>(1, plan.tiles_per_split * tune.stage_pct[r] / 100), plan.tiles_per_split - used - 1);
                 used += stages[r];
             }
             stages[r++] = plan.tiles_per_split - used;
@@ -901,6 +933,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     pp.max_norm = ix->max_norm;
     pp.qerr = (bf16 && !sq8) ? ix->w_qerr.as<float>() : nullptr;
     pp.berr = ix->bf16_err;
+    pp.tune_merge_keys = tune.merge_keys; pp.tune_merge_lists = tune.merge_lists; pp.tune_rs_cap = tune.rs_cap; pp.tune_rs_dc = tune.rs_dc;
     if (ix->kind == KIND_PQ) {  // candidates are re-scored with the distance-table arithmetic
         pp.pq_codes = ix->d_codes; pp.pq_books = ix->d_codebooks; pp.pq_m = ix->pq_m; pp.pq_dsub = ix->pq_dsub;
     }
@@ -909,7 +942,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
         pp.aux_norm = (float)(ix->sq_min_norm * (1.0 + 1e-6));
         if (bf16) pp.qaux = ix->w_qn2.as<double>() + q_pad;
     }
-    if (getenv("NEEDLE_HIP_DEBUG_TRACE"))
+    if (g_trace)
         fprintf(stderr, "[needle_hip] view %p: q %u kprime %u slices %u x %u tiles, %s, %s; base %p qop %p lists %p counts %p cand %p "
                 "queries %p out %p\n", (void*)ix, q, kprime, plan.n_splits, plan.tiles_per_split, seeded ? "seeded" : "unseeded",
                 bf16 ? "bf16" : "fp32", sp.base_op, sp.query_op, (void*)sp.lists, (void*)sp.list_counts, ix->w_cand.p,
@@ -931,7 +964,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     // set_only (the probe step of an inverted-file search): the caller needs the k nearest rows as a set, so only the
     // candidates whose first-pass scores leave their membership open are re-scored
     const bool set_mode = set_only && dense && prune && bf16 && !sq8 && ix->kind == KIND_FLAT && ix->metric == NEEDLE_METRIC_EUCLIDEAN &&
-                          !getenv("NEEDLE_HIP_DEBUG_NOSETONLY");
+                          !tune.no_set_only;
     if (prune && !set_mode) HIP_TRY(launch_prune_candidates(pp, band, c->stream));
     HIP_TRY(launch_rescore_finalize(pp, c->stream, set_mode ? &band : nullptr));
 

@@ -601,7 +601,7 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     // Thresholds start from a sample of every query's nearest list (ivf_seed_tau_kernel).  The probe slots are then
     // scanned in up to three launches (by default slots 0-3, then the rest); after each launch a query's threshold
     // is raised to the k-th best score it has listed, so the far lists only list what can still matter.
-    const bool dbg_t = getenv("NEEDLE_HIP_DEBUG") && (atoi(getenv("NEEDLE_HIP_DEBUG")) & 8);
+    const bool dbg_t = (c->tune.debug & 8u) != 0;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     if (dbg_t) HIP_TRY(hipStreamSynchronize(c->stream));
     const double t_probe_done = now();
@@ -702,14 +702,14 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     band.berr = ix->bf16_err;
     band.dim = ix->dim; band.metric = ix->metric; band.precision = scan_precision;
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    const bool no_seed = getenv("NEEDLE_HIP_DEBUG_IVF_NOSEED") != nullptr;  // development: thresholds start at -inf
+    const bool no_seed = c->tune.ivf_no_seed != 0;  // tuning: thresholds start at -inf
     if (no_seed) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ix->w_tau0.p, 0xff800000u, q, c->stream));
     if (!no_seed) {
         // rows sampled per query: fewer rows shorten this kernel (its scoring steps are serial) and weaken the thresholds
         // (more rows listed by the scans); measured on 1.25M x 384, nlist 4096, nprobe 32: 256 rows 2.34 ms per batch,
         // 128 rows 2.20, 64 rows 2.18, 32 rows 2.25
         uint32_t sample_rows = 128;
-        if (const char* e = getenv("NEEDLE_HIP_DEBUG_IVF_SEED_ROWS")) sample_rows = std::min<uint32_t>((uint32_t)atoi(e), IVF_SEED_ROWS);
+        if (c->tune.ivf_seed_rows) sample_rows = std::min<uint32_t>(c->tune.ivf_seed_rows, IVF_SEED_ROWS);
         if (bf16)
             hipLaunchKernelGGL(ivf_seed_tau_kernel<uint16_t>, dim3(q), dim3(256), 0, c->stream, d_queries, (const uint16_t*)ix->d_op_bf16,
                                dpad, sample_rows, ix->d_cinit, d_probe, d_probe_n, np, ix->d_list_pos, ix->d_list_len, ix->d_pos2id,

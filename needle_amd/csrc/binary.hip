@@ -384,7 +384,7 @@ needle_hip_status nh::binary_search_batch_device(needle_hip_index* ix, const flo
     uint32_t max_ties = 0;
     HIP_TRY(hipMemcpyAsync(&max_ties, p.max_ties, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    const bool single_scan = max_ties <= BIN_TIE_CAP && !getenv("NEEDLE_HIP_DEBUG_BINARY_TWO_SCANS");
+    const bool single_scan = max_ties <= BIN_TIE_CAP && !c->tune.binary_two_scans;
     if (single_scan) {
         HIP_TRY(launch_scan<PASS_COLLECT_ALL>(p, qt, c->stream));
     } else {

@@ -156,9 +156,9 @@ hipError_t launch_merge_select(const PostParams& p, hipStream_t stream) {
     uint32_t keys = std::min<uint32_t>(MERGE_KEYS_MAX, std::max<uint32_t>(768u, 10u * p.kprime + 128u));
     // lists per query the one-shot gather handles: all of them for a flat scan (their number is known here)
     uint32_t fast = p.list_base ? 256u : std::min<uint32_t>(1024u, std::max<uint32_t>(64u, p.n_splits));
-    if (const char* e = getenv("NEEDLE_HIP_DEBUG_MERGE")) {  // development: "keys,lists"
-        unsigned a = 0, b = 0;
-        if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 2u * KPRIME_MAX && a <= 4096 && b >= 1 && b <= 2048) { keys = a / 2 * 2; fast = b; }
+    if (p.tune_merge_keys && p.tune_merge_lists) {  // planning override
+        const uint32_t a = p.tune_merge_keys, b = p.tune_merge_lists;
+        if (a >= 2u * KPRIME_MAX && a <= 4096 && b >= 1 && b <= 2048) { keys = a / 2 * 2; fast = b; }
     }
     const size_t lds = (size_t)keys * sizeof(uint64_t) + ((size_t)fast + 1) * sizeof(uint32_t);
     static_assert(MERGE_KEYS_MAX <= 64 * 36, "register image of the merge buffer");
@@ -885,14 +885,8 @@ hipError_t launch_rescore_finalize(const PostParams& p, hipStream_t stream, cons
     // After pruning a query rarely keeps more than 64 candidates; the set-only form re-scores a dozen.
     uint32_t rcap = std::min<uint32_t>(p.kprime, set_only_band ? 32u : 64u);
     uint32_t dc = set_only_band ? 128u : 64u;
-    if (const char* e = getenv("NEEDLE_HIP_DEBUG_RSCAP")) {  // development: rows staged at a time
-        const uint32_t v = (uint32_t)atoi(e);
-        if (v >= 4 && v <= p.kprime) rcap = v;
-    }
-    if (const char* e = getenv("NEEDLE_HIP_DEBUG_RSDC")) {  // development: dimensions staged per block
-        const uint32_t v = (uint32_t)atoi(e) / 4 * 4;
-        if (v >= 4 && v <= 128) dc = v;
-    }
+    if (p.tune_rs_cap >= 4 && p.tune_rs_cap <= p.kprime) rcap = p.tune_rs_cap;  // planning overrides
+    if (p.tune_rs_dc / 4 * 4 >= 4 && p.tune_rs_dc <= 128) dc = p.tune_rs_dc / 4 * 4;
     const size_t lds = ((size_t)dc + (size_t)rcap * (dc + 4)) * sizeof(float);
     if (set_only_band)
         hipLaunchKernelGGL(rescore_finalize_kernel<true>, dim3(p.q), dim3(RS_THREADS), lds, stream, p, dc, rcap, *set_only_band);

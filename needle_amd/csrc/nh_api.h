@@ -1,6 +1,7 @@
 // Internal host-side definitions shared by the C ABI translation units.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -35,34 +36,54 @@ needle_hip_status fail(needle_hip_status st, const char* fmt, ...);
         if (_s != NEEDLE_HIP_OK) return _s;       \
     } while (0)
 
+// Process-wide development switches, set through needle_hip_set_tuning ("trace", "poison"); the library reads no
+// environment variable.
+inline std::atomic<bool> g_trace{false};   // log workspace allocations and slot hand-outs to stderr
+inline std::atomic<bool> g_poison{false};  // fresh workspace starts as all-ones: a kernel reading what nothing wrote shows up at once
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         if (p) {
-            static const bool trace_free = getenv("NEEDLE_HIP_DEBUG_TRACE") != nullptr;
-            if (trace_free) fprintf(stderr, "[needle_hip] buf %p: grows, frees %p\n", (void*)this, p);
+            if (g_trace) fprintf(stderr, "[needle_hip] buf %p: grows, frees %p\n", (void*)this, p);
             (void)hipFree(p); p = nullptr; cap = 0;
         }
         size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) { p = nullptr; return e; }
         cap = want;
-        // development: fresh workspace starts as all-ones, so that a kernel reading what nothing wrote shows up at once
-        static const bool poison = getenv("NEEDLE_HIP_DEBUG_POISON") != nullptr;
-        if (poison) { (void)hipMemset(p, 0xff, want); (void)hipDeviceSynchronize(); }
-        static const bool trace = getenv("NEEDLE_HIP_DEBUG_TRACE") != nullptr;
-        if (trace) fprintf(stderr, "[needle_hip] buf %p: %zu bytes at %p\n", (void*)this, want, p);
+        if (g_poison) { (void)hipMemset(p, 0xff, want); (void)hipDeviceSynchronize(); }
+        if (g_trace) fprintf(stderr, "[needle_hip] buf %p: %zu bytes at %p\n", (void*)this, want, p);
         return hipSuccess;
     }
     void release() {
-        static const bool trace = getenv("NEEDLE_HIP_DEBUG_TRACE") != nullptr;
-        if (trace && p) fprintf(stderr, "[needle_hip] buf %p: released %p\n", (void*)this, p);
+        if (g_trace && p) fprintf(stderr, "[needle_hip] buf %p: released %p\n", (void*)this, p);
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
     }
     template <typename T> T* as() const { return (T*)p; }
+};
+
+// Planning overrides of a context (needle_hip_set_tuning): what tests use to force a code path and what the A/B tools
+// sweep.  They move plans and cost, never results.  0 / negative = the built-in choice.
+struct Tuning {
+    uint32_t debug = 0;          // 1 selection off (timing only), 2 no threshold seeding, 4 one launch per slice, 8 print what the
+                                 // first pass listed, 16 no candidate pruning, 64 print the in-kernel clock (stamp build)
+    uint32_t splits = 0;         // slices of the base per query block
+    int32_t pre_tiles = -1;      // tiles per slice the threshold pre-pass samples
+    uint32_t kseed = 0;          // rank of the seeded threshold among the sampled group maxima
+    float band = 0.0f;           // width of the threshold band in score uncertainties
+    uint32_t stage_pct[4] = {0, 0, 0, 0};  // share of a slice per staged launch (the last launch takes the rest)
+    uint32_t n_stage_pct = 0;
+    uint32_t no_dense = 0;       // small bases take the candidate lists instead of the dense score matrix
+    uint32_t no_set_only = 0;    // the IVF probe re-scores every centroid candidate
+    uint32_t merge_keys = 0, merge_lists = 0;  // LDS keys / one-shot lists of the candidate merge
+    uint32_t rs_cap = 0, rs_dc = 0;            // exact re-score: rows staged at a time / dimensions per block
+    uint32_t ivf_no_seed = 0;    // inverted-list scan: thresholds start at -inf
+    uint32_t ivf_seed_rows = 0;  // rows of the nearest list sampled per query for the starting threshold
+    uint32_t binary_two_scans = 0;  // binary codes: always the ranked two-scan path
 };
 
 inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
@@ -76,6 +97,7 @@ struct needle_hip_ctx {
     bool profiling = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     needle_hip_metrics m{};
+    nh::Tuning tune;
     std::recursive_mutex mu;  // recursive: a host-pointer operator holds it across staging, its _device form and the copy back
     std::mutex prof_mu;  // held by a whole search while profiling is on (the events ev[] are shared by the context's indexes)
     nh::DevBuf scratch[8];  // operator-level calls

@@ -117,7 +117,7 @@ struct ScanParams {
     uint32_t kprime;
     uint32_t cap;
     uint32_t xcd_map;         // 1: n_splits % 8 == 0, splits pinned to blockIdx % 8
-    uint32_t debug;           // development switches (NEEDLE_HIP_DEBUG): 1 = selection off
+    uint32_t debug;           // nh::Tuning::debug: 1 = selection off (timing only)
     // threshold seeding: a pre-pass over the first pre_tiles tiles of every slice records, per
     // query, the maxima of 8 * n_splits disjoint row groups; the kprime-th largest of them (minus
     // two ulps) is a score at least kprime live rows exceed, so the main pass may start from it

@@ -124,6 +124,7 @@ struct PostParams {
     const float* sq_scale;    // [dim]
     uint32_t sq_stride;
     float aux_norm;           // SQ8: |min_vals| (bound check)
+    uint32_t tune_merge_keys, tune_merge_lists, tune_rs_cap, tune_rs_dc;  // planning overrides (nh::Tuning), 0 = built-in
     uint32_t* flagged;        // [q] query indices failing the bound check
     uint32_t* flag_count;     // [1]
     uint64_t* out_ids;        // [q][k]

@@ -61,11 +61,6 @@ def _destroy_handle(owner, destroy_name: str = "needle_hip_index_destroy") -> No
     ctx_alive = ctx is not None and getattr(ctx, "_h", None) is not None and bool(ctx._h.value)
     if h is not None and h.value and ctx_alive and not _lib.shutting_down():
         getattr(_lib.lib(), destroy_name)(h)
-    elif h is not None and h.value and not ctx_alive and os.environ.get("NEEDLE_HIP_DEBUG_STALE_LOG"):
-        import threading  # development: record wrappers that outlived their context
-
-        with open(os.environ["NEEDLE_HIP_DEBUG_STALE_LOG"], "a") as f:
-            f.write(f"{type(owner).__name__} handle {h.value:#x} dropped after its context, thread {threading.current_thread().name}\n")
     owner._h = C.c_void_p()
 
 
@@ -101,6 +96,26 @@ class Context:
 
     def reset_metrics(self) -> None:
         _lib.check(_lib.lib().needle_hip_reset_metrics(self._h))
+
+    def set_tuning(self, **overrides) -> None:
+        """Planning overrides (needle_hip_set_tuning): tests force a code path with them, the A/B tools sweep them.
+        `stages=(10, 25)` sets the staged-launch schedule; `reset=1` restores the built-in choices."""
+        for key, value in overrides.items():
+            if key == "stages":
+                vals = list(value) + [0] * (4 - len(value))
+                for i, pc in enumerate(vals[:4]):
+                    _lib.check(_lib.lib().needle_hip_set_tuning(self._h, f"stage{i}".encode(), float(pc)))
+            else:
+                _lib.check(_lib.lib().needle_hip_set_tuning(self._h, key.encode(), float(value)))
+
+    def apply_tuning_spec(self, spec: str | None) -> None:
+        """`key=value,key=value` as the bench tools take it (stages as `stages=10:25`)."""
+        for item in filter(None, (spec or "").split(",")):
+            key, _, val = item.partition("=")
+            if key == "stages":
+                self.set_tuning(stages=[float(x) for x in val.split(":") if x])
+            else:
+                self.set_tuning(**{key: float(val)})
 
     # ---- operator-level calls ------------------------------------------
     def batch_distance(self, metric: DistanceFunction, query, base, arith: int = _lib.ARITH_ACCEL_CHUNK4) -> np.ndarray:

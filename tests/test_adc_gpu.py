@@ -154,11 +154,11 @@ def test_binary_hamming_scan(ctx, oracle, shape):
     ix = BinaryIndex(ctx, bq, codes)
     want = obq.batch_search(queries, codes, k)
     _cmp(ix.search(queries, k), want)  # few rows at the threshold distance: one collecting scan
-    os.environ["NEEDLE_HIP_DEBUG_BINARY_TWO_SCANS"] = "1"  # the ranked two-scan path on the same data
+    ctx.set_tuning(binary_two_scans=1)  # the ranked two-scan path on the same data
     try:
         _cmp(ix.search(queries, k), want)
     finally:
-        del os.environ["NEEDLE_HIP_DEBUG_BINARY_TWO_SCANS"]
+        ctx.set_tuning(binary_two_scans=0)
     ix.close()
 
 

@@ -75,11 +75,11 @@ def test_random_flat_case(ctx, oracle, seed):
     ix = na.FlatIndex(ctx, base, m, valid=valid)
     tag = (metric, dim, n, nq, k, precision, kind, splits, valid is not None, filt is not None)
     if splits:
-        os.environ["NEEDLE_HIP_DEBUG_SPLITS"] = str(splits)
+        ctx.set_tuning(splits=splits)
     try:
         _run_twice(oracle, ix, queries, base, k, m, precision, valid, filt, nq, tag)
     finally:
-        os.environ.pop("NEEDLE_HIP_DEBUG_SPLITS", None)
+        ctx.set_tuning(splits=0)
         ix.close()
 
 

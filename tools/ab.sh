@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B timing of library variants on the headline workload: tools/ab.sh name[:ENV=VAL+ENV=VAL...] ...
+# (planning overrides go through the harness: main:NEEDLE_BENCH_TUNE=stages=15:30,pre_tiles=6)
 # (name "main" = needle_amd/lib/libneedle_hip.so, otherwise needle_amd/lib/variants/libneedle_hip_<name>.so)
 for spec in "$@"; do
   name=${spec%%:*}; envs=""

@@ -521,6 +521,7 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     ctx = na.Context(0)
+    ctx.apply_tuning_spec(os.environ.get("NEEDLE_BENCH_TUNE"))  # A/B sweeps: planning overrides, e.g. splits=64,pre_tiles=16
     oracle = None
     if not args.no_parity:
         from oracle import oracle as orc  # checker only

@@ -13,7 +13,7 @@ BEGIN, END = "// ---- generated from include/needle_hip.h by tools/gen_rust_sys.
              "// ---- generated from include/needle_hip.h: end ----"
 
 SCALARS = {"needle_hip_status": "c_int", "int": "c_int", "needle_metric": "c_int", "needle_arith": "c_int",
-           "uint64_t": "u64", "uint32_t": "u32", "uint16_t": "u16", "uint8_t": "u8", "float": "f32", "void": "c_void",
+           "uint64_t": "u64", "uint32_t": "u32", "uint16_t": "u16", "uint8_t": "u8", "float": "f32", "double": "f64", "void": "c_void",
            "char": "c_char", "needle_hip_ctx": "needle_hip_ctx", "needle_hip_index": "needle_hip_index",
            "needle_hip_comm": "needle_hip_comm", "needle_search_params": "needle_search_params",
            "needle_hip_metrics": "needle_hip_metrics"}
