@@ -105,6 +105,9 @@ extern "C" {
     pub fn needle_hip_flat_build_device(ctx: *mut needle_hip_ctx, d_base: *const f32, n: u64, dim: u32, metric: c_int, arith: c_int, valid_bitmask_host: *const u32, out: *mut *mut needle_hip_index) -> c_int;
     pub fn needle_hip_flat_build_half(ctx: *mut needle_hip_ctx, rows: *const u16, n: u64, dim: u32, half_kind: c_int, metric: c_int, arith: c_int, valid_bitmask: *const u32, out: *mut *mut needle_hip_index) -> c_int;
     pub fn needle_hip_index_set_valid_mask(index: *mut needle_hip_index, valid_bitmask: *const u32) -> c_int;
+    pub fn needle_hip_index_append(index: *mut needle_hip_index, rows: *const f32, n_new: u64, new_valid_bitmask: *const u32) -> c_int;
+    pub fn needle_hip_index_append_device(index: *mut needle_hip_index, d_rows: *const f32, n_new: u64, new_valid_bitmask_host: *const u32) -> c_int;
+    pub fn needle_hip_index_swap_remove(index: *mut needle_hip_index, pos: u64) -> c_int;
     pub fn needle_hip_index_destroy(index: *mut needle_hip_index);
     pub fn needle_hip_index_len(index: *const needle_hip_index) -> u64;
     pub fn needle_hip_index_dimensions(index: *const needle_hip_index) -> u32;

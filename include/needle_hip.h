@@ -206,6 +206,25 @@ needle_hip_status needle_hip_flat_build_half(needle_hip_ctx* ctx, const uint16_t
 needle_hip_status needle_hip_index_set_valid_mask(needle_hip_index* index,
                                                   const uint32_t* valid_bitmask);
 
+/* GpuResidentIndex::add / add_batch, src/experimental/gpu/mod.rs:1102-1160: rows
+ * appended behind the resident ones of a FLAT index; row i of the batch becomes
+ * internal id len + i.  Only the new rows cross PCIe: their operands, norms,
+ * seeds and error bounds are derived on the device and the resident arrays grow
+ * in place (capacity doubles when it runs out, moved device to device).  The
+ * result of any later search equals that of an index built from all rows at
+ * once.  new_valid_bitmask (host, bit j = row j of the batch may be returned;
+ * NULL = all) extends the live-row mask.  NaN / Inf in the batch fails with
+ * NEEDLE_HIP_ERR_INVALID_VECTOR and leaves the index unchanged.  Like `&mut
+ * self` in the reference: no search of this index may run during the call.
+ * Inverted-file and quantized indexes answer NEEDLE_HIP_ERR_UNSUPPORTED. */
+needle_hip_status needle_hip_index_append(needle_hip_index* index, const float* rows, uint64_t n_new,
+                                          const uint32_t* new_valid_bitmask);
+needle_hip_status needle_hip_index_append_device(needle_hip_index* index, const float* d_rows, uint64_t n_new,
+                                                 const uint32_t* new_valid_bitmask_host);
+/* GpuResidentIndex::remove, src/experimental/gpu/mod.rs:1198-1207
+ * (Vec::swap_remove): the last row of a FLAT index takes internal id `pos`, the
+ * index shrinks by one row.  Same exclusivity as needle_hip_index_append. */
+needle_hip_status needle_hip_index_swap_remove(needle_hip_index* index, uint64_t pos);
 void needle_hip_index_destroy(needle_hip_index* index);
 
 uint64_t needle_hip_index_len(const needle_hip_index* index);        /* Collection::len */

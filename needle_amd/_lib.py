@@ -26,7 +26,8 @@ EXPORTS = (
     "needle_hip_init", "needle_hip_shutdown", "needle_hip_last_error", "needle_hip_version",
     "needle_hip_set_profiling", "needle_hip_get_metrics", "needle_hip_reset_metrics", "needle_hip_set_tuning", "needle_hip_metric_from_str",
     "needle_hip_flat_build", "needle_hip_flat_build_rows", "needle_hip_flat_build_device", "needle_hip_flat_build_half",
-    "needle_hip_index_set_valid_mask", "needle_hip_index_destroy", "needle_hip_index_len",
+    "needle_hip_index_set_valid_mask", "needle_hip_index_append", "needle_hip_index_append_device", "needle_hip_index_swap_remove",
+    "needle_hip_index_destroy", "needle_hip_index_len",
     "needle_hip_index_dimensions", "needle_hip_batch_search", "needle_hip_batch_search_device",
     "needle_hip_batch_distance", "needle_hip_kmeans_assign", "needle_hip_merge_topk_device",
     "needle_hip_ivf_build", "needle_hip_ivf_probe", "needle_hip_ivf_list_sizes", "needle_hip_pq_build",
@@ -129,6 +130,12 @@ def lib() -> C.CDLL:
     L.needle_hip_flat_build_device.argtypes = [vp, vp, u64, u32, i32, i32, vp, C.POINTER(vp)]
     L.needle_hip_index_set_valid_mask.restype = i32
     L.needle_hip_index_set_valid_mask.argtypes = [vp, vp]
+    L.needle_hip_index_append.restype = i32
+    L.needle_hip_index_append.argtypes = [vp, vp, C.c_uint64, vp]
+    L.needle_hip_index_append_device.restype = i32
+    L.needle_hip_index_append_device.argtypes = [vp, vp, C.c_uint64, vp]
+    L.needle_hip_index_swap_remove.restype = i32
+    L.needle_hip_index_swap_remove.argtypes = [vp, C.c_uint64]
     L.needle_hip_index_destroy.restype = None
     L.needle_hip_index_destroy.argtypes = [vp]
     L.needle_hip_index_len.restype = u64

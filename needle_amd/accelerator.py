@@ -163,28 +163,30 @@ class GpuAccelerator:
 
 
 class GpuResidentIndex:
-    """`GpuResidentIndex` (src/experimental/gpu/mod.rs:1102-1213): vectors stay on the device between
-    searches; `add_batch` marks the index dirty and the next search re-uploads."""
+    """`GpuResidentIndex` (src/experimental/gpu/mod.rs:1102-1213): vectors stay on the device between searches.
+    `add` / `add_batch` queue rows on the host; the next search appends the queued rows to the resident index
+    (needle_hip_index_append: only the new rows cross PCIe).  `remove` is the reference's `swap_remove`: the last
+    vector takes the removed one's position (needle_hip_index_swap_remove, a row copy on the device)."""
 
     def __init__(self, dimensions: int, distance_type: DistanceType = DistanceType.Cosine, device: int = 0,
                  ctx: Context | None = None):
         self.ctx = ctx or Context(device)
         self.dimensions = dimensions
         self.distance_type = DistanceType(distance_type)
-        self._rows: list[np.ndarray] = []
-        self._ids: list[int] = []
+        self._ids: list[int] = []             # external id by position (resident rows first, then the queued ones)
+        self._pending: list[np.ndarray] = []  # rows added since the last search
         self._index: FlatIndex | None = None
         self.dirty = False
 
     def __len__(self) -> int:
-        return len(self._rows)
+        return len(self._ids)
 
     def add(self, id: int, vector) -> None:
         v = _f32(vector)
         if v.size != self.dimensions:
             raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
                                          f"Dimension mismatch: expected {self.dimensions}, got {v.size}")
-        self._rows.append(v)
+        self._pending.append(v)
         self._ids.append(id)
         self.dirty = True
 
@@ -194,22 +196,29 @@ class GpuResidentIndex:
 
     def remove(self, id: int) -> bool:
         try:
-            i = self._ids.index(id)
+            pos = self._ids.index(id)
         except ValueError:
             return False
-        del self._ids[i]
-        del self._rows[i]
-        self.dirty = True
+        self._sync()  # positions refer to the resident order
+        self._ids[pos] = self._ids[-1]
+        self._ids.pop()
+        self._index.swap_remove(pos)
         return True
 
+    def _sync(self) -> None:
+        """Queued rows go to the device: an append, or the first build."""
+        if self._pending:
+            rows = np.stack(self._pending)
+            self._pending = []
+            if self._index is None:
+                self._index = FlatIndex(self.ctx, rows, self.distance_type.metric(), arith=_lib.ARITH_ACCEL_CHUNK4)
+            else:
+                self._index.append(rows)
+        self.dirty = False
+
     def search(self, query, k: int) -> List[Hit]:
-        if not self._rows:
+        if not self._ids:
             return []
-        if self.dirty or self._index is None:
-            if self._index is not None:
-                self._index.close()
-            self._index = FlatIndex(self.ctx, np.stack(self._rows), self.distance_type.metric(),
-                                    arith=_lib.ARITH_ACCEL_CHUNK4)
-            self.dirty = False
-        ids, dists, counts = self._index.search(_f32(query).reshape(1, -1), min(k, len(self._rows)))
+        self._sync()
+        ids, dists, counts = self._index.search(_f32(query).reshape(1, -1), min(k, len(self._ids)))
         return [(self._ids[int(ids[0, j])], float(dists[0, j])) for j in range(int(counts[0]))]

@@ -421,6 +421,7 @@ needle_hip_status nh::finish_operands(needle_hip_index* ix, bool validate) {
     memcpy(&ix->max_norm, &bits[0], sizeof(float));
     float min_norm;
     memcpy(&min_norm, &bits[1], sizeof(float));
+    ix->min_norm = min_norm;
     // Cosine: the first pass scores rows by their true cosine (normalised in double), but the reference's f32
     // dot(b, b) underflows for rows below about 1e-19 and overflows above about 1e19, which moves its distance by
     // tens of percent or forces it to 1.0.  No bound on the first-pass score covers that, so an index holding such
@@ -451,6 +452,7 @@ static needle_hip_status flat_alloc(needle_hip_ctx* c, uint64_t n, uint32_t dim,
     ix->metric = metric;
     ix->arith = arith;
     ix->n_pad = round_up((uint32_t)n, TILE_ROWS);
+    ix->cap_pad = ix->n_pad;
     if (n > 0) {
         const size_t bytes = (size_t)ix->n_pad * dim * sizeof(float);
         hipError_t e = hipMalloc((void**)&ix->d_raw, bytes);
@@ -556,6 +558,184 @@ extern "C" needle_hip_status needle_hip_index_set_valid_mask(needle_hip_index* i
     std::lock_guard g(ix->mu);
     HIP_TRY(hipSetDevice(ix->ctx->device));
     return upload_mask(ix, valid_bitmask);
+}
+
+// ---------------------------------------------------------------------------
+// append (GpuResidentIndex::add / add_batch, src/experimental/gpu/mod.rs:1102-1160)
+// ---------------------------------------------------------------------------
+// A resident array of `rows_old` rows of `row_bytes` bytes moves to a zeroed allocation for `rows_new` rows (device to
+// device: nothing is uploaded again).
+static hipError_t grow_rows(void** p, size_t row_bytes, uint64_t rows_old, uint64_t rows_new, hipStream_t stream) {
+    if (!*p && rows_old > 0) return hipErrorInvalidValue;
+    void* fresh = nullptr;
+    hipError_t e = hipMalloc(&fresh, (size_t)rows_new * row_bytes);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync((char*)fresh + (size_t)rows_old * row_bytes, 0, (size_t)(rows_new - rows_old) * row_bytes, stream);
+    if (e == hipSuccess && rows_old > 0) e = hipMemcpyAsync(fresh, *p, (size_t)rows_old * row_bytes, hipMemcpyDeviceToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) { (void)hipFree(fresh); return e; }
+    if (*p) (void)hipFree(*p);
+    *p = fresh;
+    return hipSuccess;
+}
+
+static needle_hip_status flat_append(needle_hip_index* ix, const float* rows, bool rows_on_device, uint64_t n_new,
+                                     const uint32_t* new_valid_bitmask) {
+    if (!ix) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "index is null");
+    if (ix->kind != KIND_FLAT || ix->is_view)
+        return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "rows can be appended to flat indexes only (inverted and quantized indexes are rebuilt)");
+    if (n_new == 0) return NEEDLE_HIP_OK;
+    if (!rows) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "rows is null");
+    if (ix->n + n_new >= 0xfffffff0ull - TILE_ROWS) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "at most 2^32-272 rows per index");
+    std::lock_guard g(ix->mu);
+    needle_hip_ctx* c = ix->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t n_old = ix->n, n_all = n_old + n_new;
+    const uint32_t pad_old = ix->n_pad, pad_all = round_up((uint32_t)n_all, TILE_ROWS);
+    const uint32_t dim = ix->dim;
+    const bool first_pass = metric_has_first_pass(ix->metric);
+    if (first_pass && ix->dpad_f32 == 0) {  // an index built empty: the operand layout was never fixed
+        ix->dpad_f32 = round_up(dim, flat_scan_kstep(NEEDLE_PRECISION_FP32));
+        ix->op_f32_alias = ix->metric != NEEDLE_METRIC_COSINE && ix->dpad_f32 == dim;
+    }
+    // 1. capacity: every resident array moves to an allocation of twice the rows when the new rows do not fit
+    if (pad_all > ix->cap_pad) {
+        const uint32_t cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * ix->cap_pad, pad_all), 0xffffff80ull);
+        const uint64_t have = pad_old;
+        HIP_TRY(grow_rows((void**)&ix->d_raw, (size_t)dim * sizeof(float), have, cap, c->stream));
+        if (first_pass) {
+            if (ix->op_f32_alias) ix->d_op_f32 = ix->d_raw;
+            else HIP_TRY(grow_rows((void**)&ix->d_op_f32, (size_t)ix->dpad_f32 * sizeof(float), have, cap, c->stream));
+            HIP_TRY(grow_rows((void**)&ix->d_norms, sizeof(float), have, cap, c->stream));
+            if (ix->metric == NEEDLE_METRIC_EUCLIDEAN) HIP_TRY(grow_rows((void**)&ix->d_cinit, sizeof(float), have, cap, c->stream));
+            if (ix->d_op_bf16) HIP_TRY(grow_rows((void**)&ix->d_op_bf16, (size_t)ix->dpad_bf16 * sizeof(uint16_t), have, cap, c->stream));
+        }
+        ix->cap_pad = cap;
+    }
+    // 2. the new rows go behind the old ones and are checked there (validate_insert_input, src/collection/validation.rs:44-52);
+    //    a rejected batch leaves the index as it was
+    float* tail = ix->d_raw + (size_t)n_old * dim;
+    HIP_TRY(hipMemcpyAsync(tail, rows, (size_t)n_new * dim * sizeof(float), rows_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                           c->stream));
+    uint32_t* d_flag = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_flag, 4 * sizeof(uint32_t)));
+    uint32_t bad = 0xffffffffu;
+    hipError_t e = launch_validate_rows(tail, n_new, dim, d_flag, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && bad != 0xffffffffu) {
+        (void)hipMemsetAsync(tail, 0, (size_t)(pad_all - n_old) * dim * sizeof(float), c->stream);  // padding rows are zero again
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(d_flag);
+        return fail(NEEDLE_HIP_ERR_INVALID_VECTOR, "Invalid vector: appended row %u contains NaN or Inf", bad);
+    }
+    if (e == hipSuccess && pad_all > n_all)  // (an earlier, rejected batch may have left values behind the last row)
+        e = hipMemsetAsync(ix->d_raw + (size_t)n_all * dim, 0, (size_t)(pad_all - n_all) * dim * sizeof(float), c->stream);
+    // 3. operands, norms, seeds and error bounds of the new rows only; the running extrema continue from the index's
+    if (e == hipSuccess && first_pass) {
+        uint32_t bits[4];
+        memcpy(&bits[0], &ix->max_norm, 4);
+        memcpy(&bits[1], &ix->min_norm, 4);
+        memcpy(&bits[2], &ix->bf16_err, 4);
+        bits[3] = 0;
+        const bool normalize = ix->metric == NEEDLE_METRIC_COSINE;
+        e = hipMemcpyAsync(d_flag, bits, sizeof(bits), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess)
+            e = launch_row_prep(tail, n_new, dim, ix->dpad_f32, normalize,
+                                ix->op_f32_alias ? nullptr : ix->d_op_f32 + (size_t)n_old * ix->dpad_f32, nullptr,
+                                ix->d_cinit ? ix->d_cinit + n_old : nullptr, ix->d_norms + n_old, nullptr, d_flag, nullptr, nullptr, c->stream);
+        if (e == hipSuccess && ix->d_op_bf16)
+            e = launch_row_prep(tail, n_new, dim, ix->dpad_bf16, normalize, nullptr, ix->d_op_bf16 + (size_t)n_old * ix->dpad_bf16, nullptr,
+                                nullptr, nullptr, nullptr, nullptr, d_flag + 2, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(bits, d_flag, sizeof(bits), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) {
+            memcpy(&ix->max_norm, &bits[0], 4);
+            memcpy(&ix->min_norm, &bits[1], 4);
+            if (ix->d_op_bf16) memcpy(&ix->bf16_err, &bits[2], 4);
+            ix->cos_norm_unsafe = ix->metric == NEEDLE_METRIC_COSINE && (ix->min_norm < 1e-15f || ix->max_norm > 1e15f);
+        }
+    }
+    (void)hipFree(d_flag);
+    HIP_TRY(e);
+    // 4. the live-row mask: bits of the new rows behind the old ones (all set where no mask is given)
+    if (ix->d_valid || new_valid_bitmask) {
+        const size_t w_old = (n_old + 31) / 32, w_all = (n_all + 31) / 32;
+        std::vector<uint32_t> m;
+        try {
+            m.assign(w_all, 0u);
+        } catch (...) {
+            return fail(NEEDLE_HIP_ERR_OUT_OF_MEMORY, "host allocation failed");
+        }
+        if (ix->d_valid) {
+            HIP_TRY(hipMemcpyAsync(m.data(), ix->d_valid, w_old * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        } else {
+            for (uint64_t i = 0; i < n_old; ++i) m[i >> 5] |= 1u << (i & 31);
+        }
+        for (uint64_t j = 0; j < n_new; ++j) {
+            const uint64_t i = n_old + j;
+            const bool live = !new_valid_bitmask || ((new_valid_bitmask[j >> 5] >> (j & 31)) & 1u);
+            if (live) m[i >> 5] |= 1u << (i & 31); else m[i >> 5] &= ~(1u << (i & 31));
+        }
+        ix->n = n_all;  // upload_mask sizes the copy from the row count
+        const needle_hip_status st = upload_mask(ix, m.data());
+        if (st != NEEDLE_HIP_OK) { ix->n = n_old; return st; }
+    }
+    ix->n = n_all;
+    ix->n_pad = pad_all;
+    return NEEDLE_HIP_OK;
+}
+
+// GpuResidentIndex::remove, gpu/mod.rs:1198-1207 (Vec::swap_remove): the last row takes the place of row `pos`, the
+// index shrinks by one.  Row copies stay on the device; the norm and error extrema remain valid as bounds.
+extern "C" needle_hip_status needle_hip_index_swap_remove(needle_hip_index* ix, uint64_t pos) {
+    if (!ix) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "index is null");
+    if (ix->kind != KIND_FLAT || ix->is_view) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "rows can be removed from flat indexes only");
+    if (pos >= ix->n) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "row %llu out of range (%llu rows)", (unsigned long long)pos,
+                                  (unsigned long long)ix->n);
+    std::lock_guard g(ix->mu);
+    needle_hip_ctx* c = ix->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t last = ix->n - 1;
+    auto move_row = [&](void* arr, size_t row_bytes) -> hipError_t {  // arr[pos] = arr[last]; arr[last] = 0 (padding rows are zero)
+        if (!arr) return hipSuccess;
+        char* a = (char*)arr;
+        hipError_t e = hipSuccess;
+        if (pos != last) e = hipMemcpyAsync(a + pos * row_bytes, a + last * row_bytes, row_bytes, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(a + last * row_bytes, 0, row_bytes, c->stream);
+        return e;
+    };
+    HIP_TRY(move_row(ix->d_raw, (size_t)ix->dim * sizeof(float)));
+    if (!ix->op_f32_alias) HIP_TRY(move_row(ix->d_op_f32, (size_t)ix->dpad_f32 * sizeof(float)));
+    HIP_TRY(move_row(ix->d_op_bf16, (size_t)ix->dpad_bf16 * sizeof(uint16_t)));
+    HIP_TRY(move_row(ix->d_cinit, sizeof(float)));
+    HIP_TRY(move_row(ix->d_norms, sizeof(float)));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (ix->d_valid) {  // the moved row keeps its bit
+        const size_t words = (ix->n + 31) / 32;
+        std::vector<uint32_t> m(words);
+        HIP_TRY(hipMemcpy(m.data(), ix->d_valid, words * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const bool live = (m[last >> 5] >> (last & 31)) & 1u;
+        if (live) m[pos >> 5] |= 1u << (pos & 31); else m[pos >> 5] &= ~(1u << (pos & 31));
+        m[last >> 5] &= ~(1u << (last & 31));
+        ix->n = last;
+        if (last == 0) { (void)hipFree(ix->d_valid); ix->d_valid = nullptr; }
+        else ST_TRY(upload_mask(ix, m.data()));
+    }
+    ix->n = last;
+    ix->n_pad = round_up((uint32_t)last, TILE_ROWS);
+    return NEEDLE_HIP_OK;
+}
+
+extern "C" needle_hip_status needle_hip_index_append(needle_hip_index* ix, const float* rows, uint64_t n_new,
+                                                     const uint32_t* new_valid_bitmask) {
+    return flat_append(ix, rows, false, n_new, new_valid_bitmask);
+}
+
+extern "C" needle_hip_status needle_hip_index_append_device(needle_hip_index* ix, const float* d_rows, uint64_t n_new,
+                                                            const uint32_t* new_valid_bitmask_host) {
+    return flat_append(ix, d_rows, true, n_new, new_valid_bitmask_host);
 }
 
 extern "C" void needle_hip_index_destroy(needle_hip_index* ix) { nh::index_free(ix); }
@@ -664,7 +844,8 @@ needle_hip_status nh::ensure_bf16_copy(needle_hip_index* ix) {
     if (ix->d_op_bf16) return NEEDLE_HIP_OK;
     needle_hip_ctx* c = ix->ctx;
     ix->dpad_bf16 = flat_scan_bf16_dpad(ix->dim);
-    const size_t bytes = (size_t)ix->n_pad * ix->dpad_bf16 * sizeof(uint16_t);
+    // (a flat index that has grown by appends keeps every resident array at its capacity, this copy included)
+    const size_t bytes = (size_t)std::max(ix->n_pad, ix->cap_pad) * ix->dpad_bf16 * sizeof(uint16_t);
     uint16_t* d = nullptr;
     uint32_t* d_bits = nullptr;
     HIP_TRY(hipMalloc((void**)&d, bytes));

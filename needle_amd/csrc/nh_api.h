@@ -125,6 +125,8 @@ struct needle_hip_index {
     float* d_norms = nullptr;      // [n_pad]
     uint32_t* d_valid = nullptr;   // live-row bitmask (by row id) or null
     float max_norm = 0.0f;
+    float min_norm = 3.40282347e+38f;  // smallest non-zero row norm (cosine: decides cos_norm_unsafe; kept for appends)
+    uint32_t cap_pad = 0;          // flat index: rows the resident arrays are allocated for (>= n_pad; grows by doubling on append)
     bool cos_norm_unsafe = false;  // cosine index holding a row whose norm the reference's f32 arithmetic cannot represent
     uint32_t bf16_extra_slack = 0; // candidates kept per query beyond the default bf16 slack (grows when batches leave queries undecided)
     float bf16_err = 0.0f;         // max over rows of |row operand - its bf16 copy| (set with d_op_bf16); SQ8: max |code vector|

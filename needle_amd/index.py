@@ -283,6 +283,34 @@ class FlatIndex:
         vm = _mask_words(valid, self.n)
         _lib.check(_lib.lib().needle_hip_index_set_valid_mask(self._h, vm.ctypes.data if vm is not None else None))
 
+    def append(self, rows, valid=None) -> None:
+        """Rows appended behind the resident ones (needle_hip_index_append): row j of the batch becomes internal id
+        len + j; only the new rows are uploaded.  `rows` is a host array or a contiguous float32 device tensor."""
+        if hasattr(rows, "data_ptr"):
+            if rows.dim() != 2 or str(rows.dtype) != "torch.float32" or not rows.is_contiguous() or int(rows.shape[1]) != self.dim:
+                raise ValueError("device rows must be a contiguous float32 [n, dim] tensor")
+            m = int(rows.shape[0])
+            vm = _mask_words(valid, m)
+            _wait_for_producer(rows)
+            _lib.check(_lib.lib().needle_hip_index_append_device(self._h, rows.data_ptr(), m,
+                                                                  vm.ctypes.data if vm is not None else None))
+        else:
+            r = _f32(rows)
+            if r.ndim == 1:
+                r = r.reshape(1, -1)
+            if r.ndim != 2 or r.shape[1] != self.dim:
+                raise _lib.DimensionMismatch(_lib.ERR_DIMENSION_MISMATCH,
+                                             f"Dimension mismatch: expected {self.dim}, got {r.shape[-1]}")
+            m = int(r.shape[0])
+            vm = _mask_words(valid, m)
+            _lib.check(_lib.lib().needle_hip_index_append(self._h, r.ctypes.data, m, vm.ctypes.data if vm is not None else None))
+        self.n += m
+
+    def swap_remove(self, pos: int) -> None:
+        """The last row takes internal id `pos`; the index shrinks by one (Vec::swap_remove, needle_hip_index_swap_remove)."""
+        _lib.check(_lib.lib().needle_hip_index_swap_remove(self._h, int(pos)))
+        self.n -= 1
+
     def search(self, queries, k: int, *, precision: str = "fp32", filter_mask=None):
         """Host arrays in, host arrays out: (ids[q,k] uint64, dists[q,k] float32, counts[q] uint32)."""
         q = _f32(queries)
