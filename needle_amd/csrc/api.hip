@@ -217,6 +217,7 @@ void nh::index_free(needle_hip_index* ix) {
     if (ix->d_cinit) (void)hipFree(ix->d_cinit);
     if (ix->d_norms) (void)hipFree(ix->d_norms);
     if (ix->d_valid) (void)hipFree(ix->d_valid);
+    if (ix->d_unsafe) (void)hipFree(ix->d_unsafe);
     release_workspace(ix);
     handle_retire(ix);
 }
@@ -229,7 +230,7 @@ static void release_workspace(needle_hip_index* ix) {
     for (DevBuf* b : {&ix->w_qraw, &ix->w_qop, &ix->w_qn2, &ix->w_lists, &ix->w_lcnt, &ix->w_cand, &ix->w_candn,
                       &ix->w_tau, &ix->w_flagged, &ix->w_flagcnt, &ix->w_filter, &ix->w_premax, &ix->w_tau0, &ix->x_keys, &ix->x_u32,
                       &ix->x_u64, &ix->x_sel, &ix->x_mask, &ix->v_probe_ids, &ix->v_probe_d, &ix->v_probe_n, &ix->v_probe32,
-                      &ix->v_items, &ix->v_itemq, &ix->v_lbase, &ix->w_qerr, &ix->r_idx, &ix->r_q, &ix->r_ids, &ix->r_dists, &ix->r_cnt, &ix->v_regroup, &ix->b_work, &ix->w_cinit, &ix->w_cscore, &ix->w_pqtab})
+                      &ix->v_items, &ix->v_itemq, &ix->v_lbase, &ix->w_qerr, &ix->r_idx, &ix->r_q, &ix->r_ids, &ix->r_dists, &ix->r_cnt, &ix->v_regroup, &ix->b_work, &ix->w_cinit, &ix->w_cscore, &ix->w_pqtab, &ix->w_extra})
         b->release();
 }
 
@@ -241,6 +242,7 @@ static void sync_view(needle_hip_index* v, const needle_hip_index* p, needle_hip
     v->d_raw = p->d_raw; v->d_op_f32 = p->d_op_f32; v->op_f32_alias = p->op_f32_alias; v->d_op_bf16 = p->d_op_bf16;
     v->dpad_f32 = p->dpad_f32; v->dpad_bf16 = p->dpad_bf16; v->d_cinit = p->d_cinit; v->d_norms = p->d_norms;
     v->d_valid = p->d_valid; v->max_norm = p->max_norm; v->cos_norm_unsafe = p->cos_norm_unsafe;
+    v->d_unsafe = p->d_unsafe; v->n_unsafe = p->n_unsafe;
     v->bf16_extra_slack = p->bf16_extra_slack; v->bf16_err = p->bf16_err;
     v->nlist = p->nlist; v->d_list_pos = p->d_list_pos; v->d_list_len = p->d_list_len; v->d_pos2id = p->d_pos2id;
     v->d_codes = p->d_codes; v->d_codes_gm = p->d_codes_gm; v->d_codebooks = p->d_codebooks; v->pq_m = p->pq_m; v->pq_dsub = p->pq_dsub;
@@ -286,8 +288,10 @@ static bool search_uses_bf16_copy(const needle_hip_index* ix, const needle_searc
     if (ix->kind == KIND_BINARY || ix->n == 0 || sp->k == 0) return false;
     if (ix->kind == KIND_IVF && ix->pq_m) return false;  // built with the index
     if (sp->precision != NEEDLE_PRECISION_BF16 || flat_scan_bf16_dpad(ix->dim) == 0) return false;
-    if (ix->kind == KIND_FLAT && (!metric_has_first_pass(ix->metric) || ix->cos_norm_unsafe)) return false;
-    return choose_kprime((uint32_t)std::min<uint64_t>(sp->k, ix->n), NEEDLE_PRECISION_BF16) <= (uint32_t)KPRIME_MAX;
+    if (ix->kind == KIND_FLAT && !metric_has_first_pass(ix->metric)) return false;
+    const uint32_t kp = choose_kprime((uint32_t)std::min<uint64_t>(sp->k, ix->n), NEEDLE_PRECISION_BF16);
+    if (ix->cos_norm_unsafe && (uint64_t)kp + ix->n_unsafe > (uint32_t)KPRIME_MAX) return false;  // served by the exact scan
+    return kp <= (uint32_t)KPRIME_MAX;
 }
 
 nh::SlotLease::SlotLease(needle_hip_index* parent, const needle_search_params* params) : parent_(parent) {
@@ -422,11 +426,36 @@ needle_hip_status nh::finish_operands(needle_hip_index* ix, bool validate) {
     float min_norm;
     memcpy(&min_norm, &bits[1], sizeof(float));
     ix->min_norm = min_norm;
-    // Cosine: the first pass scores rows by their true cosine (normalised in double), but the reference's f32
-    // dot(b, b) underflows for rows below about 1e-19 and overflows above about 1e19, which moves its distance by
-    // tens of percent or forces it to 1.0.  No bound on the first-pass score covers that, so an index holding such
-    // a row serves every query from the exact scan.
-    ix->cos_norm_unsafe = ix->metric == NEEDLE_METRIC_COSINE && (min_norm < 1e-15f || ix->max_norm > 1e15f);
+    return refresh_unsafe_rows(ix);
+}
+
+// Cosine: the first pass scores rows by their true cosine (normalised in double), but the reference's f32 dot(b, b)
+// underflows for rows below about 1e-19 and overflows above about 1e19, which moves its distance by tens of percent or
+// forces it to 1.0.  No bound on a first-pass score covers that.  Such rows are therefore kept out of every first pass
+// (accumulator seed -inf) and listed on the side: a search re-scores them exactly for every query, next to the
+// query's own candidates, and the bound check speaks about the other rows only.  An index with more of them than a
+// search can carry as extra candidates serves that search from the exact scan.
+needle_hip_status nh::refresh_unsafe_rows(needle_hip_index* ix) {
+    if (ix->kind != KIND_FLAT || ix->metric != NEEDLE_METRIC_COSINE || ix->n == 0 || !ix->d_norms) {
+        ix->n_unsafe = 0;
+        ix->cos_norm_unsafe = false;
+        return NEEDLE_HIP_OK;
+    }
+    // the running extrema bound every row's norm (they are not lowered when rows are removed)
+    if (!(ix->min_norm < 1e-15f || ix->max_norm > 1e15f) && !ix->d_unsafe) return NEEDLE_HIP_OK;
+    needle_hip_ctx* c = ix->ctx;
+    const size_t rows_alloc = std::max(ix->n_pad, ix->cap_pad);
+    if (!ix->d_cinit) {
+        HIP_TRY(hipMalloc((void**)&ix->d_cinit, rows_alloc * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(ix->d_cinit, 0, rows_alloc * sizeof(float), c->stream));
+    }
+    if (!ix->d_unsafe) HIP_TRY(hipMalloc((void**)&ix->d_unsafe, (UNSAFE_ROWS_MAX + 1) * sizeof(uint32_t)));
+    uint32_t count = 0;
+    HIP_TRY(launch_unsafe_rows(ix->d_norms, ix->n, ix->d_cinit, ix->d_unsafe, UNSAFE_ROWS_MAX, ix->d_unsafe + UNSAFE_ROWS_MAX, c->stream));
+    HIP_TRY(hipMemcpyAsync(&count, ix->d_unsafe + UNSAFE_ROWS_MAX, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ix->n_unsafe = count;
+    ix->cos_norm_unsafe = count > 0;
     return NEEDLE_HIP_OK;
 }
 
@@ -607,7 +636,8 @@ static needle_hip_status flat_append(needle_hip_index* ix, const float* rows, bo
             if (ix->op_f32_alias) ix->d_op_f32 = ix->d_raw;
             else HIP_TRY(grow_rows((void**)&ix->d_op_f32, (size_t)ix->dpad_f32 * sizeof(float), have, cap, c->stream));
             HIP_TRY(grow_rows((void**)&ix->d_norms, sizeof(float), have, cap, c->stream));
-            if (ix->metric == NEEDLE_METRIC_EUCLIDEAN) HIP_TRY(grow_rows((void**)&ix->d_cinit, sizeof(float), have, cap, c->stream));
+            if (ix->metric == NEEDLE_METRIC_EUCLIDEAN || ix->d_cinit)
+                HIP_TRY(grow_rows((void**)&ix->d_cinit, sizeof(float), have, cap, c->stream));
             if (ix->d_op_bf16) HIP_TRY(grow_rows((void**)&ix->d_op_bf16, (size_t)ix->dpad_bf16 * sizeof(uint16_t), have, cap, c->stream));
         }
         ix->cap_pad = cap;
@@ -643,7 +673,8 @@ static needle_hip_status flat_append(needle_hip_index* ix, const float* rows, bo
         if (e == hipSuccess)
             e = launch_row_prep(tail, n_new, dim, ix->dpad_f32, normalize,
                                 ix->op_f32_alias ? nullptr : ix->d_op_f32 + (size_t)n_old * ix->dpad_f32, nullptr,
-                                ix->d_cinit ? ix->d_cinit + n_old : nullptr, ix->d_norms + n_old, nullptr, d_flag, nullptr, nullptr, c->stream);
+                                ix->metric == NEEDLE_METRIC_EUCLIDEAN ? ix->d_cinit + n_old : nullptr, ix->d_norms + n_old, nullptr, d_flag,
+                                nullptr, nullptr, c->stream);
         if (e == hipSuccess && ix->d_op_bf16)
             e = launch_row_prep(tail, n_new, dim, ix->dpad_bf16, normalize, nullptr, ix->d_op_bf16 + (size_t)n_old * ix->dpad_bf16, nullptr,
                                 nullptr, nullptr, nullptr, nullptr, d_flag + 2, c->stream);
@@ -653,7 +684,6 @@ static needle_hip_status flat_append(needle_hip_index* ix, const float* rows, bo
             memcpy(&ix->max_norm, &bits[0], 4);
             memcpy(&ix->min_norm, &bits[1], 4);
             if (ix->d_op_bf16) memcpy(&ix->bf16_err, &bits[2], 4);
-            ix->cos_norm_unsafe = ix->metric == NEEDLE_METRIC_COSINE && (ix->min_norm < 1e-15f || ix->max_norm > 1e15f);
         }
     }
     (void)hipFree(d_flag);
@@ -684,7 +714,7 @@ static needle_hip_status flat_append(needle_hip_index* ix, const float* rows, bo
     }
     ix->n = n_all;
     ix->n_pad = pad_all;
-    return NEEDLE_HIP_OK;
+    return refresh_unsafe_rows(ix);  // (cosine: the new rows may hold norms the first pass cannot bound)
 }
 
 // GpuResidentIndex::remove, gpu/mod.rs:1198-1207 (Vec::swap_remove): the last row takes the place of row `pos`, the
@@ -725,7 +755,7 @@ extern "C" needle_hip_status needle_hip_index_swap_remove(needle_hip_index* ix, 
     }
     ix->n = last;
     ix->n_pad = round_up((uint32_t)last, TILE_ROWS);
-    return NEEDLE_HIP_OK;
+    return refresh_unsafe_rows(ix);  // (the side list names rows by id)
 }
 
 extern "C" needle_hip_status needle_hip_index_append(needle_hip_index* ix, const float* rows, uint64_t n_new,
@@ -902,8 +932,11 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     uint32_t kprime = choose_kprime(std::min(k, n), precision);
     // bf16: an index whose earlier batches left many queries undecided keeps more candidates per query (see below)
     if (precision == NEEDLE_PRECISION_BF16) kprime = std::min<uint32_t>(round_up(kprime + ix->bf16_extra_slack, 16), KPRIME_MAX);
+    // cosine rows with norms no first pass can bound ride along as extra candidates of every query, when they fit
+    const bool unsafe_extra = ix->cos_norm_unsafe && ix->d_unsafe && ix->n_unsafe <= UNSAFE_ROWS_MAX &&
+                              (uint64_t)kprime + ix->n_unsafe <= (uint32_t)KPRIME_MAX;
     const bool exact_only = precision == NEEDLE_PRECISION_EXACT_SCAN || (!sq8 && !metric_has_first_pass(ix->metric)) ||
-                            kprime > KPRIME_MAX || ix->cos_norm_unsafe;
+                            kprime > KPRIME_MAX || (ix->cos_norm_unsafe && !unsafe_extra);
     if (exact_only) {
         ST_TRY(run_exact(ix, d_queries, nullptr, q, k, d_filter, d_out_ids, d_out_dists, d_out_counts));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1114,6 +1147,13 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     pp.max_norm = ix->max_norm;
     pp.qerr = (bf16 && !sq8) ? ix->w_qerr.as<float>() : nullptr;
     pp.berr = ix->bf16_err;
+    if (unsafe_extra) {
+        HIP_TRY(ix->w_extra.ensure((UNSAFE_ROWS_MAX + 1) * sizeof(uint32_t)));
+        uint32_t* ex = ix->w_extra.as<uint32_t>();
+        HIP_TRY(launch_unsafe_live(ix->d_unsafe, ix->n_unsafe, ix->d_valid, d_filter, ex, ex + UNSAFE_ROWS_MAX, c->stream));
+        pp.extra_ids = ex;
+        pp.extra_n = ex + UNSAFE_ROWS_MAX;
+    }
     pp.tune_merge_keys = tune.merge_keys; pp.tune_merge_lists = tune.merge_lists; pp.tune_rs_cap = tune.rs_cap; pp.tune_rs_dc = tune.rs_dc;
     if (ix->kind == KIND_PQ) {  // candidates are re-scored with the distance-table arithmetic
         pp.pq_codes = ix->d_codes; pp.pq_books = ix->d_codebooks; pp.pq_m = ix->pq_m; pp.pq_dsub = ix->pq_dsub;

@@ -228,6 +228,7 @@ __device__ inline void dense_ord4(const PostParams& p, const float* __restrict__
         bool ok = r < p.n;
         if (masked && ok && p.valid) ok = bit_set(p.valid, r);
         if (masked && ok && p.filter) ok = bit_set(p.filter, r);
+        if (ok && p.extra_n && v[j] == -INFINITY) ok = false;  // a row every query re-scores anyway (seeded -inf): not a candidate twice
         o4[j] = ok ? f2ord(v[j]) : 0u;
     }
 }
@@ -696,14 +697,16 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams
     __shared__ uint32_t s_ord[SET_ONLY ? KPRIME_MAX : 1];
     __shared__ uint32_t s_misc[4];  // SET_ONLY: ordinals of s_k and s_k+1, number of certain / in-between candidates
     const uint32_t q = blockIdx.x, j = threadIdx.x;
-    uint32_t nc = min(p.cand_n[q], p.kprime);
+    const uint32_t n_own = min(p.cand_n[q], p.kprime);
+    uint32_t nc = n_own;
+    if (!SET_ONLY && p.extra_n) nc = min(n_own + *p.extra_n, (uint32_t)KPRIME_MAX);  // (the host keeps kprime + extras within KPRIME_MAX)
     const uint32_t k_eff = min(p.k, nc);
     uint32_t emit = k_eff, emit_base = 0;  // hits still to be chosen by exact distance, and their first output slot
     uint64_t key = ~0ull;
     float d = 0.0f;
     uint32_t id = 0, pos = 0;
     if (j < nc) {
-        pos = p.cand_ids[(uint64_t)q * p.kprime + j];
+        pos = j < n_own ? p.cand_ids[(uint64_t)q * p.kprime + j] : p.extra_ids[j - n_own];
         id = p.pos2id ? p.pos2id[pos] : pos;
     }
     if (j < KPRIME_MAX) spos[j] = pos;

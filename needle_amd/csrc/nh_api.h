@@ -128,6 +128,9 @@ struct needle_hip_index {
     float min_norm = 3.40282347e+38f;  // smallest non-zero row norm (cosine: decides cos_norm_unsafe; kept for appends)
     uint32_t cap_pad = 0;          // flat index: rows the resident arrays are allocated for (>= n_pad; grows by doubling on append)
     bool cos_norm_unsafe = false;  // cosine index holding a row whose norm the reference's f32 arithmetic cannot represent
+    uint32_t* d_unsafe = nullptr;  // those rows (up to UNSAFE_ROWS_MAX of them): re-scored for every query beside its candidates,
+    uint32_t n_unsafe = 0;         // and kept out of every first pass by -inf accumulator seeds; a search that cannot afford
+                                   // n_unsafe extra candidates (or an index with more of them) takes the exact scan
     uint32_t bf16_extra_slack = 0; // candidates kept per query beyond the default bf16 slack (grows when batches leave queries undecided)
     float bf16_err = 0.0f;         // max over rows of |row operand - its bf16 copy| (set with d_op_bf16); SQ8: max |code vector|
     std::mutex mu;
@@ -153,6 +156,7 @@ struct needle_hip_index {
     // per-search workspace (grow-only)
     nh::DevBuf w_qraw, w_qop, w_qn2, w_lists, w_lcnt, w_cand, w_candn, w_tau, w_flagged, w_flagcnt, w_filter, w_premax,
         w_tau0;
+    nh::DevBuf w_extra;  // [UNSAFE_ROWS_MAX + 1]: the unsafe rows this search may return, then their count
     nh::DevBuf w_cscore; // [q][kprime] first-pass scores of the selected candidates (pruning before the exact re-score)
     nh::DevBuf w_cinit; // [n_pad] accumulator seeds of a search under row masks (dead rows at -inf)
     nh::DevBuf w_qerr;  // [q_pad] |query operand - its bf16 copy|
@@ -172,6 +176,9 @@ struct needle_hip_index {
 
 namespace nh {
 constexpr size_t MAX_SEARCH_SLOTS = 4;
+constexpr uint32_t UNSAFE_ROWS_MAX = 192;
+// cosine flat index: (re)derives the list of rows with unrepresentable norms and their seeds from d_norms (api.hip)
+needle_hip_status refresh_unsafe_rows(needle_hip_index* ix);
 struct SearchSlot {
     needle_hip_ctx ctx;       // device and CU count of the parent context; stream, events and metrics of its own
     needle_hip_index ix;      // view of the parent index

@@ -70,6 +70,11 @@ hipError_t launch_row_prep(const float* d_rows, uint64_t n, uint32_t dim, uint32
                            float* d_norms, double* d_norm2, uint32_t* d_max_norm_bits,
                            float* d_bf16_err /* [n] |operand - bf16 operand|, nullable */,
                            uint32_t* d_max_bf16_err_bits /* running maximum of it, nullable */, hipStream_t stream);
+// Cosine rows with a norm f32 cannot square (prep.hip): list and count them, seeds[i] = -inf for them and 0 otherwise.
+hipError_t launch_unsafe_rows(const float* d_norms, uint64_t n, float* d_seeds, uint32_t* d_list, uint32_t cap, uint32_t* d_count,
+                              hipStream_t stream);
+hipError_t launch_unsafe_live(const uint32_t* d_list, uint32_t n_list, const uint32_t* d_valid, const uint32_t* d_filter, uint32_t* d_out,
+                              uint32_t* d_out_n, hipStream_t stream);
 // 0 if every value is finite, else 1 + index of the first row holding a NaN / Inf.
 hipError_t launch_validate_rows(const float* d_rows, uint64_t n, uint32_t dim, uint32_t* d_bad_row_plus1,
                                 hipStream_t stream);
@@ -124,6 +129,8 @@ struct PostParams {
     const float* sq_scale;    // [dim]
     uint32_t sq_stride;
     float aux_norm;           // SQ8: |min_vals| (bound check)
+    const uint32_t* extra_ids;  // rows every query re-scores beside its own candidates (cosine rows whose norm the first pass
+    const uint32_t* extra_n;    // cannot bound), and how many: device pointers, null = none
     uint32_t tune_merge_keys, tune_merge_lists, tune_rs_cap, tune_rs_dc;  // planning overrides (nh::Tuning), 0 = built-in
     uint32_t* flagged;        // [q] query indices failing the bound check
     uint32_t* flag_count;     // [1]

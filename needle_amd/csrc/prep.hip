@@ -261,6 +261,48 @@ __global__ __launch_bounds__(256) void masked_seed_kernel(const float* __restric
     out[i] = live ? (seed ? seed[i] : 0.0f) : -INFINITY;
 }
 
+// Cosine rows whose norm the reference's f32 dot(b, b) cannot represent (it underflows below about 1e-19 and overflows
+// above about 1e19; the cut is taken well inside): they are listed (at most `cap` of them; the count keeps running) and
+// their accumulator seeds set to -inf, so that no first pass ever lists them -- the search re-scores them for every query.
+__global__ __launch_bounds__(256) void unsafe_rows_kernel(const float* __restrict__ norms, uint64_t n, float* __restrict__ seeds,
+                                                          uint32_t* __restrict__ list, uint32_t cap, uint32_t* __restrict__ count) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = norms[i];
+    const bool bad = v != 0.0f && !(v >= 1e-15f && v <= 1e15f);
+    seeds[i] = bad ? -INFINITY : 0.0f;
+    if (bad) {
+        const uint32_t at = atomicAdd(count, 1u);
+        if (at < cap) list[at] = (uint32_t)i;
+    }
+}
+
+hipError_t launch_unsafe_rows(const float* d_norms, uint64_t n, float* d_seeds, uint32_t* d_list, uint32_t cap, uint32_t* d_count,
+                              hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess || n == 0) return e;
+    hipLaunchKernelGGL(unsafe_rows_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_norms, n, d_seeds, d_list, cap, d_count);
+    return hipGetLastError();
+}
+
+// the listed rows a search may return (live and admitted by the filter), in any order
+__global__ __launch_bounds__(256) void unsafe_live_kernel(const uint32_t* __restrict__ list, uint32_t n_list,
+                                                          const uint32_t* __restrict__ valid, const uint32_t* __restrict__ filter,
+                                                          uint32_t* __restrict__ out, uint32_t* __restrict__ out_n) {
+    for (uint32_t i = threadIdx.x; i < n_list; i += 256) {
+        const uint32_t row = list[i];
+        if ((!valid || bit_set(valid, row)) && (!filter || bit_set(filter, row))) out[atomicAdd(out_n, 1u)] = row;
+    }
+}
+
+hipError_t launch_unsafe_live(const uint32_t* d_list, uint32_t n_list, const uint32_t* d_valid, const uint32_t* d_filter, uint32_t* d_out,
+                              uint32_t* d_out_n, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(d_out_n, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess || n_list == 0) return e;
+    hipLaunchKernelGGL(unsafe_live_kernel, dim3(1), dim3(256), 0, stream, d_list, n_list, d_valid, d_filter, d_out, d_out_n);
+    return hipGetLastError();
+}
+
 hipError_t launch_masked_seed(const float* d_seed, const uint32_t* d_valid, const uint32_t* d_filter, uint32_t n, uint32_t n_pad,
                               float* d_out, hipStream_t stream) {
     if (n_pad == 0) return hipSuccess;

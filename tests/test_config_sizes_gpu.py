@@ -222,19 +222,50 @@ def test_pq_per_gpu_share(ctx, oracle):
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 def test_cosine_rows_with_unrepresentable_norms(ctx, oracle, precision):
     """Rows scaled by 1e-23 (the reference's f32 dot(b, b) underflows: norm 0, distance forced to 1.0) and by 1e20 (it
-    overflows: norm inf, distance 1 - dot / inf): the first pass ranks such rows by their true cosine, so an index
-    holding them must not trust its bound; the result is the reference arithmetic's all the same."""
+    overflows: norm inf, distance 1 - dot / inf): no bound ties a first-pass score to such a distance, so these rows stay
+    out of the first pass and every query re-scores them beside its own candidates -- the result is the reference
+    arithmetic's, and no query falls back to the exact scan.  Small base (dense score matrix) and large (candidate lists);
+    with masks; after an append that brings more such rows; and with more of them than a search can carry (exact scan)."""
     import needle_amd as na
 
     rng = np.random.default_rng(91)
-    base = rng.standard_normal((6000, 64)).astype(F)
-    queries = rng.standard_normal((40, 64)).astype(F)
-    queries[:10] = base[100:110] + F(0.01) * rng.standard_normal((10, 64)).astype(F)  # nearest rows are about to be rescaled
-    base[100:105] *= F(1e-23)
-    base[105:110] *= F(1e20)
-    oi, od, oc = oracle.flat_batch_search(queries, base, 10, oracle.COSINE)
+    for n in (6000, 30000):
+        base = rng.standard_normal((n, 64)).astype(F)
+        queries = rng.standard_normal((40, 64)).astype(F)
+        queries[:10] = base[100:110] + F(0.01) * rng.standard_normal((10, 64)).astype(F)  # nearest rows are about to be rescaled
+        base[100:105] *= F(1e-23)
+        base[105:110] *= F(1e20)
+        base[n - 1] *= F(1e-23)
+        valid = np.ones(n, dtype=bool)
+        valid[[101, 106, 500]] = False
+        filt = rng.random(n) < 0.7
+        filt[100:110:2] = True
+        ix = na.FlatIndex(ctx, base, na.DistanceFunction.Cosine, valid=valid)
+        ctx.reset_metrics()
+        for fm in (None, filt):
+            oi, od, oc = oracle.flat_batch_search(queries, base, 10, oracle.COSINE, valid=valid, filt=fm)
+            ids, dists, counts = ix.search(queries, 10, precision=precision, filter_mask=fm)
+            assert np.array_equal(counts, oc) and np.array_equal(ids, oi), (n, fm is not None)
+            assert np.array_equal(_bits(dists), _bits(od))
+        assert ctx.metrics()["fallback_queries"] == 0
+        # an append with two more such rows: the side list follows
+        more = rng.standard_normal((300, 64)).astype(F)
+        more[7] *= F(1e21)
+        more[8] = queries[3] * F(1e-24)
+        ix.append(more)
+        all_rows = np.concatenate([base, more])
+        all_valid = np.concatenate([valid, np.ones(300, dtype=bool)])
+        oi, od, oc = oracle.flat_batch_search(queries, all_rows, 10, oracle.COSINE, valid=all_valid)
+        ids, dists, counts = ix.search(queries, 10, precision=precision)
+        assert np.array_equal(counts, oc) and np.array_equal(ids, oi) and np.array_equal(_bits(dists), _bits(od))
+        assert ctx.metrics()["fallback_queries"] == 0
+        ix.close()
+    # 250 such rows are more than a search carries as extra candidates: the exact scan answers, still the reference's bits
+    base = rng.standard_normal((5000, 32)).astype(F)
+    base[1000:1250] *= F(1e-22)
+    queries = rng.standard_normal((12, 32)).astype(F)
     ix = na.FlatIndex(ctx, base, na.DistanceFunction.Cosine)
+    oi, od, oc = oracle.flat_batch_search(queries, base, 10, oracle.COSINE)
     ids, dists, counts = ix.search(queries, 10, precision=precision)
-    assert np.array_equal(counts, oc) and np.array_equal(ids, oi)
-    assert np.array_equal(_bits(dists), _bits(od))
+    assert np.array_equal(counts, oc) and np.array_equal(ids, oi) and np.array_equal(_bits(dists), _bits(od))
     ix.close()
