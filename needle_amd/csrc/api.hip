@@ -230,7 +230,7 @@ static void release_workspace(needle_hip_index* ix) {
     for (DevBuf* b : {&ix->w_qraw, &ix->w_qop, &ix->w_qn2, &ix->w_lists, &ix->w_lcnt, &ix->w_cand, &ix->w_candn,
                       &ix->w_tau, &ix->w_flagged, &ix->w_flagcnt, &ix->w_filter, &ix->w_premax, &ix->w_tau0, &ix->x_keys, &ix->x_u32,
                       &ix->x_u64, &ix->x_sel, &ix->x_mask, &ix->v_probe_ids, &ix->v_probe_d, &ix->v_probe_n, &ix->v_probe32,
-                      &ix->v_items, &ix->v_itemq, &ix->v_lbase, &ix->w_qerr, &ix->r_idx, &ix->r_q, &ix->r_ids, &ix->r_dists, &ix->r_cnt, &ix->v_regroup, &ix->b_work, &ix->w_cinit, &ix->w_cscore, &ix->w_pqtab, &ix->w_extra})
+                      &ix->v_items, &ix->v_itemq, &ix->v_lbase, &ix->w_qerr, &ix->r_idx, &ix->r_q, &ix->r_ids, &ix->r_dists, &ix->r_cnt, &ix->v_regroup, &ix->v_probe_sel, &ix->b_work, &ix->w_cinit, &ix->w_cscore, &ix->w_pqtab, &ix->w_extra})
         b->release();
 }
 
@@ -921,7 +921,7 @@ needle_hip_status nh::ensure_bf16_copy(needle_hip_index* ix) {
 // Device-resident search of one batch of at most QB queries.
 needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k,
                                                int precision, const uint32_t* d_filter, uint64_t* d_out_ids,
-                                               float* d_out_dists, uint32_t* d_out_counts, bool set_only) {
+                                               float* d_out_dists, uint32_t* d_out_counts, bool set_only, bool defer_flagged) {
     needle_hip_ctx* c = ix->ctx;
     const uint32_t n = (uint32_t)ix->n;
     const bool sq8 = ix->kind == KIND_SQ8;
@@ -938,6 +938,10 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     const bool exact_only = precision == NEEDLE_PRECISION_EXACT_SCAN || (!sq8 && !metric_has_first_pass(ix->metric)) ||
                             kprime > KPRIME_MAX || (ix->cos_norm_unsafe && !unsafe_extra);
     if (exact_only) {
+        if (defer_flagged) {  // nothing is left open: the caller will read a zero
+            HIP_TRY(ix->w_flagcnt.ensure(sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(ix->w_flagcnt.p, 0, sizeof(uint32_t), c->stream));
+        }
         ST_TRY(run_exact(ix, d_queries, nullptr, q, k, d_filter, d_out_ids, d_out_dists, d_out_counts));
         HIP_TRY(hipStreamSynchronize(c->stream));
         std::lock_guard g(c->mu);
@@ -1188,6 +1192,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
                           !tune.no_set_only;
     if (prune && !set_mode) HIP_TRY(launch_prune_candidates(pp, band, c->stream));
     HIP_TRY(launch_rescore_finalize(pp, c->stream, set_mode ? &band : nullptr));
+    if (defer_flagged) return NEEDLE_HIP_OK;  // (this pass's device time is then not added to the metrics)
 
     uint32_t n_flagged = 0;
     HIP_TRY(hipMemcpyAsync(&n_flagged, pp.flag_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));

@@ -88,7 +88,7 @@ __device__ __forceinline__ void seed_load8(const uint16_t* p, float (&v)[8]) {
 template <typename T>  // rows: the f32 rows, or their bf16 copy (row stride ld elements)
 __global__ __launch_bounds__(256) void ivf_seed_tau_kernel(const float* __restrict__ queries, const T* __restrict__ rows, uint32_t ld,
                                                            uint32_t sample_rows, const float* __restrict__ cinit, const uint32_t* __restrict__ probe,
-                                                           const uint32_t* __restrict__ probe_n, uint32_t np,
+                                                           const uint32_t* __restrict__ probe_n, uint32_t np, uint32_t nlist,
                                                            const uint32_t* __restrict__ list_pos,
                                                            const uint32_t* __restrict__ list_len,
                                                            const uint32_t* __restrict__ pos2id, const uint32_t* __restrict__ valid,
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void ivf_seed_tau_kernel(const float* __restri
     ord[threadIdx.x] = 0u;
     __syncthreads();
     if (probe_n[q] > 0) {  // block-uniform
-        const uint32_t l = probe[(uint64_t)q * np];
+        const uint32_t l = min(probe[(uint64_t)q * np], nlist - 1);
         const uint32_t p0 = list_pos[l], len = min(list_len[l], min(sample_rows, IVF_SEED_ROWS));
         const float* qv = queries + (uint64_t)q * dim;
         // every wave scores a quarter of the sample (the steps of the scoring loop are serial: an even split keeps the
@@ -202,7 +202,8 @@ struct RegroupBufs {
     uint32_t *cnt, *fill, *pair_off, *item_off;  // [3 * nlist] (+1 for the offsets)
     uint32_t *qlists, *lbase, *lbase_dev;        // candidate lists of every query; exclusive sums ([q + 1]; x lpe)
     uint32_t* slot_rel;                          // [q][np] first candidate list of (query, slot), relative to the query
-    uint32_t* totals;                            // [0] candidate lists, [1..3] end of stage 0..2 in items, [4] most lists of one query
+    uint32_t* totals;                            // [0] candidate lists, [1..3] end of stage 0..2 in items, [4] most lists of one query,
+                                                 // [5..8] item bounds of the three launches
     uint2* itemq;
     nh::IvfItem* items;
     uint32_t q, np, nlist, run, item_queries, lpe, b1, b2;
@@ -226,11 +227,11 @@ __global__ __launch_bounds__(256) void ivf_regroup_count_kernel(RegroupBufs g) {
 #pragma unroll
         for (uint32_t u = 0; u < 8; ++u) l[u] = g.probe[(uint64_t)i * g.np + min(s0 + u, n - 1)];
 #pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) r[u] = rg_runs(g, l[u]);
+        for (uint32_t u = 0; u < 8; ++u) r[u] = l[u] < g.nlist ? rg_runs(g, l[u]) : 0u;
 #pragma unroll
         for (uint32_t u = 0; u < 8; ++u) {
             const uint32_t sl = s0 + u;
-            if (sl < n) {
+            if (sl < n && l[u] < g.nlist) {  // (a list id out of range is ignored, here and in the scatter)
                 g.slot_rel[(uint64_t)i * g.np + sl] = at;
                 at += r[u];
                 atomicAdd(&g.cnt[rg_stage(g, sl) * g.nlist + l[u]], 1u);
@@ -332,6 +333,11 @@ __global__ __launch_bounds__(1024) void ivf_regroup_scan_kernel(RegroupBufs g) {
         g.totals[2] = g.item_off[2 * g.nlist];
         g.totals[3] = g.item_off[SL];
         g.totals[4] = most;
+        // items of stage r: [totals[5 + r], totals[6 + r]) -- what a list-scan launch reads as its bounds
+        g.totals[5] = 0;
+        g.totals[6] = g.item_off[g.nlist];
+        g.totals[7] = g.item_off[2 * g.nlist];
+        g.totals[8] = g.item_off[SL];
     }
 }
 
@@ -340,7 +346,9 @@ __global__ __launch_bounds__(256) void ivf_regroup_scatter_kernel(RegroupBufs g)
     if (t >= g.q * g.np) return;
     const uint32_t i = t / g.np, sl = t % g.np;
     if (sl >= min(g.probe_n[i], g.np)) return;
-    const uint32_t l = g.probe[t], e = rg_stage(g, sl) * g.nlist + l;
+    const uint32_t l = g.probe[t];
+    if (l >= g.nlist) return;
+    const uint32_t e = rg_stage(g, sl) * g.nlist + l;
     const uint32_t at = g.pair_off[e] + atomicAdd(&g.fill[e], 1u);
     g.itemq[at] = make_uint2(i, g.lbase[i] + g.slot_rel[t]);
 }
@@ -512,7 +520,10 @@ extern "C" needle_hip_status needle_hip_ivf_list_sizes(const needle_hip_index* i
 
 // Coarse step on device-resident queries: v_probe32 [q][np] list ids (u32), v_probe_n [q].
 // set_only: the lists in any order (the search regroups them by list); otherwise ascending by (distance, list).
-static needle_hip_status ivf_probe_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t np, bool set_only) {
+// defer: the search goes on without waiting to learn whether a query's probe set is still open (the caller reads
+// ix->centroids->w_flagcnt at its own final synchronisation and re-runs those queries).
+static needle_hip_status ivf_probe_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t np, bool set_only,
+                                          bool defer = false) {
     needle_hip_ctx* c = ix->ctx;
     HIP_TRY(ix->v_probe_ids.ensure((size_t)q * np * sizeof(uint64_t)));
     HIP_TRY(ix->v_probe_d.ensure((size_t)q * np * sizeof(float)));
@@ -524,7 +535,7 @@ static needle_hip_status ivf_probe_device(needle_hip_index* ix, const float* d_q
         // (an fp32 first pass over a few thousand centroids measured slower: 5.3 against 3.9 ms per 10K-query batch)
         ST_TRY(flat_search_batch_device(ix->centroids, d_queries, q, np, NEEDLE_PRECISION_BF16, nullptr,
                                         ix->v_probe_ids.as<uint64_t>(), ix->v_probe_d.as<float>(),
-                                        ix->v_probe_n.as<uint32_t>(), set_only));
+                                        ix->v_probe_n.as<uint32_t>(), set_only, defer));
     }
     const uint32_t total = q * np;
     hipLaunchKernelGGL(ivf_narrow_probe_kernel, dim3((total + 255) / 256), dim3(256), 0, c->stream,
@@ -560,40 +571,35 @@ extern "C" needle_hip_status needle_hip_ivf_probe(needle_hip_index* ix, const fl
     return NEEDLE_HIP_OK;
 }
 
-needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k,
-                                              uint32_t nprobe, int precision, const uint32_t* d_filter,
-                                              uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts) {
-    needle_hip_ctx* c = ix->ctx;
-    const double t_entry = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    const uint32_t np = std::min(nprobe, ix->nlist);
-    if (np == 0) {  // no list probed: no candidates
-        HIP_TRY(launch_fill_empty(d_out_ids, d_out_dists, d_out_counts, q, k, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        return NEEDLE_HIP_OK;
-    }
-    if (np > K_MAX) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "nprobe = %u exceeds %d", np, K_MAX);
-    ST_TRY(ivf_probe_device(ix, d_queries, q, np, true));
-    const uint32_t* d_probe = ix->v_probe32.as<uint32_t>();
-    const uint32_t* d_probe_n = ix->v_probe_n.as<uint32_t>();
+// Gathers the probe lists of the queries named by sel into a compact [n_sel][np] block (re-run of queries whose probe
+// set the deferred coarse step left open).
+__global__ __launch_bounds__(256) void ivf_gather_probe_kernel(const uint32_t* __restrict__ sel, uint32_t n_sel, uint32_t np,
+                                                               const uint32_t* __restrict__ probe, const uint32_t* __restrict__ probe_n,
+                                                               uint32_t* __restrict__ out_probe, uint32_t* __restrict__ out_n) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_sel * np) return;
+    const uint32_t i = t / np, j = t % np, src = sel[i];
+    out_probe[t] = probe[(uint64_t)src * np + j];
+    if (j == 0) out_n[i] = probe_n[src];
+}
 
-    // bf16 is a hint, as in the flat search: dimensions beyond the register-resident query block use fp32
-    const bool pq = ix->pq_m != 0;  // lists of PQ codes: only the bf16 copy of the decoded rows exists, so bf16 it is
-    bool bf16 = (precision == NEEDLE_PRECISION_BF16 || pq) && flat_scan_bf16_dpad(ix->dim) != 0;
-    if (bf16 && choose_kprime((uint32_t)std::min<uint64_t>(k, ix->n), NEEDLE_PRECISION_BF16) > KPRIME_MAX) bf16 = false;
+// Everything behind the coarse step: regrouping, list scan, merge, exact re-score, bound check.  Nothing in here waits
+// for the device; h_flagged[0] (host) receives the number of queries the bound check left open once the caller has
+// synchronised the stream (their indices: ix->w_flagged).  shared_* : the bf16 query operand, |q|^2 and rounding errors
+// the coarse step prepared for the same queries (null: prepared here).
+static needle_hip_status ivf_scan_probed(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k, uint32_t np, bool bf16,
+                                         const uint32_t* d_filter, const uint32_t* d_probe, const uint32_t* d_probe_n,
+                                         uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, const void* shared_qop,
+                                         const double* shared_qn2, const float* shared_qerr, uint32_t* h_flagged) {
+    needle_hip_ctx* c = ix->ctx;
+    const bool pq = ix->pq_m != 0;
     const int scan_precision = bf16 ? NEEDLE_PRECISION_BF16 : NEEDLE_PRECISION_FP32;
     const uint32_t lpe = bf16 ? flat_scan_bf16_lists_per_slice() : 1;  // candidate lists per (query, list run): the bf16 kernel keeps one per lane group
     const uint32_t kprime = choose_kprime((uint32_t)std::min<uint64_t>(k, ix->n), scan_precision);
-    const bool exact_only = precision == NEEDLE_PRECISION_EXACT_SCAN || kprime > KPRIME_MAX || (pq && !bf16);
-    if (exact_only) {
-        ST_TRY(run_exact(ix, d_queries, nullptr, q, k, d_filter, d_out_ids, d_out_dists, d_out_counts, d_probe, d_probe_n, np));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        std::lock_guard g(c->mu);
-        c->m.fallback_queries += q;
-        return NEEDLE_HIP_OK;
-    }
 
-    // Regroup the (query, probed list) pairs by list ON THE DEVICE (ivf_regroup_* kernels above); the host reads
-    // back five counters.
+    // Regroup the (query, probed list) pairs by list ON THE DEVICE (ivf_regroup_* kernels above).  The host reads
+    // nothing back: every size below is an upper bound it can derive from the list lengths, and the list-scan launches
+    // take their real item ranges from device memory (workgroups beyond them leave at once).
     // Work items.  A list is cut into runs of at most `run` row tiles, so that a long list (hub centroid) becomes
     // many workgroups instead of one long one; every (query, probed list, run) owns a candidate list of its own,
     // numbered consecutively per query: query i owns lists list_base[i] .. list_base[i+1]-1.  `run` doubles until the
@@ -602,22 +608,34 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     // scanned in up to three launches (by default slots 0-3, then the rest); after each launch a query's threshold
     // is raised to the k-th best score it has listed, so the far lists only list what can still matter.
     const bool dbg_t = (c->tune.debug & 8u) != 0;
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    if (dbg_t) HIP_TRY(hipStreamSynchronize(c->stream));
-    const double t_probe_done = now();
     const uint32_t max_lists_per_query = std::max<uint32_t>(np, 2048);  // bounds the list bookkeeping, not correctness
     const uint32_t item_queries = bf16 ? flat_scan_bf16_ivf_queries_per_block(flat_scan_bf16_dpad(ix->dim)) : (uint32_t)TILE_QUERIES;
     uint32_t run = 8;
+    uint64_t worst = 0;  // most candidate lists one query can own: the runs of the np longest lists
     for (; run < (1u << 20); run *= 2) {
-        uint64_t worst = 0;
+        worst = 0;
         for (uint32_t i = 0; i < np; ++i) worst += std::max<uint32_t>(1, (ix->list_tiles_desc[i] + run - 1) / run);
         if (worst <= max_lists_per_query) break;
     }
+    uint64_t runs_all = 0;  // runs of all lists together, and the most runs of one list
+    const uint32_t max_runs = std::max<uint32_t>(1, (ix->list_tiles_desc.empty() ? 0u : ix->list_tiles_desc[0] + run - 1) / run);
+    for (uint32_t t : ix->list_tiles_desc) runs_all += std::max<uint32_t>(1, (t + run - 1) / run);
     uint32_t bounds[4] = {0, 0, std::min<uint32_t>(4, np), np};  // with seeded thresholds: slots 0-3, refresh, the rest
+    // items of stage r: per (list, run) one item per item_queries pairs, rounded up once per (list, run) holding pairs
+    uint64_t item_cap[3], items_cap = 0;
+    for (int r = 0; r < 3; ++r) {
+        const uint64_t pairs = (uint64_t)q * (bounds[r + 1] - bounds[r]);
+        item_cap[r] = pairs == 0 ? 0 : std::min<uint64_t>(runs_all, pairs * max_runs) + (pairs / item_queries) * max_runs;
+        items_cap += item_cap[r];
+    }
+    const uint64_t lists_cap = (uint64_t)q * worst * lpe;
+    if (items_cap >= 0x7fffffffull || lists_cap >= 0x7fffffffull)
+        return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "IVF batch of %u queries x %u probes over these lists exceeds the work-item bookkeeping; "
+                    "search fewer queries per call", q, np);
     RegroupBufs rg{};
     {
         const uint32_t SL = 3 * ix->nlist;
-        const size_t words = (size_t)4 * SL + 2 + (size_t)q + (size_t)q + 1 + (size_t)q * np + 8;
+        const size_t words = (size_t)4 * SL + 2 + (size_t)q + (size_t)q + 1 + (size_t)q * np + 16;
         HIP_TRY(ix->v_regroup.ensure(words * sizeof(uint32_t)));
         uint32_t* w = ix->v_regroup.as<uint32_t>();
         rg.cnt = w; rg.fill = w + SL; rg.pair_off = w + 2 * (size_t)SL; rg.item_off = rg.pair_off + SL + 1;
@@ -627,33 +645,29 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     }
     HIP_TRY(ix->v_lbase.ensure((size_t)(q + 1) * sizeof(uint32_t)));
     HIP_TRY(ix->v_itemq.ensure(std::max<size_t>((size_t)q * np, 1) * sizeof(uint2)));
+    HIP_TRY(ix->v_items.ensure(std::max<size_t>(items_cap, 1) * sizeof(IvfItem)));
     rg.lbase_dev = ix->v_lbase.as<uint32_t>();
     rg.probe = d_probe; rg.probe_n = d_probe_n; rg.list_len = ix->d_list_len; rg.list_pos = ix->d_list_pos;
     rg.q = q; rg.np = np; rg.nlist = ix->nlist; rg.run = run; rg.item_queries = item_queries; rg.lpe = lpe;
     rg.b1 = bounds[1]; rg.b2 = bounds[2];
-    hipLaunchKernelGGL(ivf_regroup_count_kernel, dim3((q + 255) / 256), dim3(256), 0, c->stream, rg);
-    hipLaunchKernelGGL(ivf_regroup_scan_kernel, dim3(1), dim3(1024), 0, c->stream, rg);
-    HIP_TRY(hipGetLastError());
-    uint32_t totals[8] = {0};
-    HIP_TRY(hipMemcpyAsync(totals, rg.totals, sizeof(totals), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    const uint32_t total_lists = totals[0] * lpe;  // device numbering: entry y owns lists lpe*y .. lpe*y + lpe-1
-    const uint32_t item_end[3] = {totals[1], totals[2], totals[3]};
-    const uint32_t busiest = totals[4], n_items = totals[3];
-    HIP_TRY(ix->v_items.ensure(std::max<size_t>(n_items, 1) * sizeof(IvfItem)));
     rg.itemq = ix->v_itemq.as<uint2>();
     rg.items = ix->v_items.as<IvfItem>();
+    hipLaunchKernelGGL(ivf_regroup_count_kernel, dim3((q + 255) / 256), dim3(256), 0, c->stream, rg);
+    hipLaunchKernelGGL(ivf_regroup_scan_kernel, dim3(1), dim3(1024), 0, c->stream, rg);
     hipLaunchKernelGGL(ivf_regroup_scatter_kernel, dim3((q * np + 255) / 256), dim3(256), 0, c->stream, rg);
     hipLaunchKernelGGL(ivf_regroup_items_kernel, dim3((3 * ix->nlist + 255) / 256), dim3(256), 0, c->stream, rg);
     HIP_TRY(hipGetLastError());
+    const uint32_t total_lists = (uint32_t)lists_cap;  // device numbering: entry y owns lists lpe*y .. lpe*y + lpe-1
 
-    const double t_items_done = now();
     if (bf16) ST_TRY(ensure_bf16_copy(ix));
     const uint32_t dpad = bf16 ? ix->dpad_bf16 : ix->dpad_f32, cap = list_cap(kprime);
     const size_t elt = bf16 ? 2 : 4;
-    HIP_TRY(ix->w_qop.ensure((size_t)q * dpad * elt));
-    HIP_TRY(ix->w_qn2.ensure((size_t)q * sizeof(double)));
-    if (bf16) HIP_TRY(ix->w_qerr.ensure((size_t)q * sizeof(float)));
+    const bool shared = bf16 && shared_qop && shared_qn2 && shared_qerr;
+    if (!shared) {
+        HIP_TRY(ix->w_qop.ensure((size_t)q * dpad * elt));
+        HIP_TRY(ix->w_qn2.ensure((size_t)q * sizeof(double)));
+        if (bf16) HIP_TRY(ix->w_qerr.ensure((size_t)q * sizeof(float)));
+    }
     HIP_TRY(ix->w_lists.ensure((size_t)std::max<uint32_t>(total_lists, 1) * cap * sizeof(uint2)));
     HIP_TRY(ix->w_lcnt.ensure((size_t)std::max<uint32_t>(total_lists, 1) * sizeof(uint32_t)));
     HIP_TRY(ix->w_cand.ensure((size_t)q * kprime * sizeof(uint32_t)));
@@ -661,16 +675,20 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     HIP_TRY(ix->w_tau.ensure((size_t)q * sizeof(float)));
     HIP_TRY(ix->w_flagged.ensure((size_t)q * sizeof(uint32_t)));
     HIP_TRY(ix->w_flagcnt.ensure(sizeof(uint32_t)));
-    HIP_TRY(hipMemsetAsync(ix->w_qop.p, 0, (size_t)q * dpad * elt, c->stream));
     HIP_TRY(hipMemsetAsync(ix->w_lcnt.p, 0, (size_t)std::max<uint32_t>(total_lists, 1) * sizeof(uint32_t), c->stream));
     HIP_TRY(hipMemsetAsync(ix->w_flagcnt.p, 0, sizeof(uint32_t), c->stream));
-    HIP_TRY(launch_row_prep(d_queries, q, ix->dim, dpad, false, bf16 ? nullptr : ix->w_qop.as<float>(),
-                            bf16 ? ix->w_qop.as<uint16_t>() : nullptr, nullptr, nullptr, ix->w_qn2.as<double>(), nullptr,
-                            bf16 ? ix->w_qerr.as<float>() : nullptr, nullptr, c->stream));
+    if (!shared) {
+        HIP_TRY(hipMemsetAsync(ix->w_qop.p, 0, (size_t)q * dpad * elt, c->stream));
+        HIP_TRY(launch_row_prep(d_queries, q, ix->dim, dpad, false, bf16 ? nullptr : ix->w_qop.as<float>(),
+                                bf16 ? ix->w_qop.as<uint16_t>() : nullptr, nullptr, nullptr, ix->w_qn2.as<double>(), nullptr,
+                                bf16 ? ix->w_qerr.as<float>() : nullptr, nullptr, c->stream));
+    }
+    const double* d_qn2 = shared ? shared_qn2 : ix->w_qn2.as<double>();
+    const float* d_qerr = bf16 ? (shared ? shared_qerr : ix->w_qerr.as<float>()) : nullptr;
 
     ScanParams sp{};
     sp.base_op = bf16 ? (const void*)ix->d_op_bf16 : (const void*)ix->d_op_f32;
-    sp.query_op = ix->w_qop.p;
+    sp.query_op = shared ? shared_qop : ix->w_qop.p;
     sp.cinit = ix->d_cinit;
     if (ix->d_valid || d_filter) {
         HIP_TRY(ix->w_cinit.ensure((size_t)ix->n_pad * sizeof(float)));
@@ -696,9 +714,9 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     HIP_TRY(ix->w_tau0.ensure((size_t)q * sizeof(float)));
     sp.tau0 = ix->w_tau0.as<float>();
     TauBand band{};
-    band.qn2 = ix->w_qn2.as<double>();
+    band.qn2 = d_qn2;
     band.bmax = ix->max_norm;
-    band.qerr = bf16 ? ix->w_qerr.as<float>() : nullptr;
+    band.qerr = d_qerr;
     band.berr = ix->bf16_err;
     band.dim = ix->dim; band.metric = ix->metric; band.precision = scan_precision;
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
@@ -712,29 +730,30 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
         if (c->tune.ivf_seed_rows) sample_rows = std::min<uint32_t>(c->tune.ivf_seed_rows, IVF_SEED_ROWS);
         if (bf16)
             hipLaunchKernelGGL(ivf_seed_tau_kernel<uint16_t>, dim3(q), dim3(256), 0, c->stream, d_queries, (const uint16_t*)ix->d_op_bf16,
-                               dpad, sample_rows, ix->d_cinit, d_probe, d_probe_n, np, ix->d_list_pos, ix->d_list_len, ix->d_pos2id,
+                               dpad, sample_rows, ix->d_cinit, d_probe, d_probe_n, np, ix->nlist, ix->d_list_pos, ix->d_list_len, ix->d_pos2id,
                                ix->d_valid, d_filter, ix->dim, sp.kseed, band, ix->w_tau0.as<float>());
         else
             hipLaunchKernelGGL(ivf_seed_tau_kernel<float>, dim3(q), dim3(256), 0, c->stream, d_queries, (const float*)ix->d_raw, ix->dim,
-                               sample_rows, ix->d_cinit, d_probe, d_probe_n, np, ix->d_list_pos, ix->d_list_len, ix->d_pos2id,
+                               sample_rows, ix->d_cinit, d_probe, d_probe_n, np, ix->nlist, ix->d_list_pos, ix->d_list_len, ix->d_pos2id,
                                ix->d_valid, d_filter, ix->dim, sp.kseed, band, ix->w_tau0.as<float>());
     }
     HIP_TRY(hipGetLastError());
+    bool launched = false;
     for (int r = 0; r < 3; ++r) {
-        const uint32_t i0 = r ? item_end[r - 1] : 0u, i1 = item_end[r];
-        if (i1 == i0) continue;
-        if (i0 > 0)
-            HIP_TRY(launch_tau_refresh(sp, busiest * lpe, ix->w_tau0.as<float>(), band, c->stream, ix->v_lbase.as<uint32_t>()));
+        if (item_cap[r] == 0) continue;
+        if (launched)
+            HIP_TRY(launch_tau_refresh(sp, (uint32_t)worst * lpe, ix->w_tau0.as<float>(), band, c->stream, ix->v_lbase.as<uint32_t>()));
         ScanParams spr = sp;
-        spr.items = sp.items + i0;
-        HIP_TRY(launch_ivf_scan(scan_precision, spr, i1 - i0, c->stream));
+        spr.item_bounds = rg.totals + 5 + r;
+        HIP_TRY(launch_ivf_scan(scan_precision, spr, (uint32_t)item_cap[r], c->stream));
+        launched = true;
     }
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
 
     PostParams pp{};
     pp.base_raw = ix->d_raw;
     pp.query_raw = d_queries;
-    pp.qnorm2 = ix->w_qn2.as<double>();
+    pp.qnorm2 = d_qn2;
     pp.lists = sp.lists;
     pp.list_counts = sp.list_counts;
     pp.list_base = ix->v_lbase.as<uint32_t>();
@@ -748,10 +767,10 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     pp.out_ids = d_out_ids;
     pp.out_dists = d_out_dists;
     pp.out_counts = d_out_counts;
-    pp.q = q; pp.n = ix->n_pad; pp.dim = ix->dim; pp.k = k; pp.kprime = kprime; pp.cap = cap; pp.n_splits = busiest * lpe;
+    pp.q = q; pp.n = ix->n_pad; pp.dim = ix->dim; pp.k = k; pp.kprime = kprime; pp.cap = cap; pp.n_splits = (uint32_t)worst * lpe;
     pp.metric = ix->metric; pp.arith = ix->arith; pp.precision = scan_precision;
     pp.max_norm = ix->max_norm;
-    pp.qerr = bf16 ? ix->w_qerr.as<float>() : nullptr;
+    pp.qerr = d_qerr;
     pp.berr = ix->bf16_err;
     if (pq) {  // candidates are re-scored with ProductQuantizer::asymmetric_distance on the codes (ivf.rs:540)
         pp.pq_codes = ix->d_codes; pp.pq_books = ix->d_codebooks; pp.pq_m = ix->pq_m; pp.pq_dsub = ix->pq_dsub; pp.pq_asym = 1;
@@ -761,36 +780,118 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     HIP_TRY(launch_merge_select(pp, c->stream));
     HIP_TRY(launch_prune_candidates(pp, band, c->stream));
     HIP_TRY(launch_rescore_finalize(pp, c->stream));
-
-    uint32_t n_flagged = 0;
-    HIP_TRY(hipMemcpyAsync(&n_flagged, pp.flag_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    double dbg_listed = -1.0;
+    HIP_TRY(hipMemcpyAsync(h_flagged, pp.flag_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     if (dbg_t) {
-        std::vector<uint32_t> lc(total_lists);
-        HIP_TRY(hipMemcpy(lc.data(), ix->w_lcnt.p, (size_t)total_lists * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint32_t totals[9] = {0};
+        HIP_TRY(hipMemcpyAsync(totals, rg.totals, sizeof(totals), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::vector<uint32_t> lc((size_t)totals[0] * lpe);
+        HIP_TRY(hipMemcpy(lc.data(), ix->w_lcnt.p, lc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         uint64_t tot = 0;
         for (uint32_t v : lc) tot += std::min(v, kprime);
-        dbg_listed = (double)tot / q;
+        fprintf(stderr, "[needle_hip] ivf: %u queries, %u items (grids sized for %llu), %u candidate lists (sized for %u; busiest query %u, "
+                "run %u tiles), undecided %u, listed %.1f per query\n", q, totals[3], (unsigned long long)items_cap, totals[0] * lpe,
+                total_lists, totals[4], run, *h_flagged, (double)tot / q);
     }
-    if (dbg_t)
-        fprintf(stderr, "[needle_hip] ivf: %u queries, %u items, %u candidate lists (busiest query %u, run %u tiles); probe %.2f ms, "
-                "regroup %.2f ms, device scan+post %.2f ms, undecided %u, listed %.1f per query\n", q, n_items, total_lists,
-                busiest, run, t_probe_done - t_entry, t_items_done - t_probe_done, now() - t_items_done, n_flagged, dbg_listed);
+    return NEEDLE_HIP_OK;
+}
+
+needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k,
+                                              uint32_t nprobe, int precision, const uint32_t* d_filter,
+                                              uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts) {
+    needle_hip_ctx* c = ix->ctx;
+    const uint32_t np = std::min(nprobe, ix->nlist);
+    if (np == 0) {  // no list probed: no candidates
+        HIP_TRY(launch_fill_empty(d_out_ids, d_out_dists, d_out_counts, q, k, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return NEEDLE_HIP_OK;
+    }
+    if (np > K_MAX) return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "nprobe = %u exceeds %d", np, K_MAX);
+    // bf16 is a hint, as in the flat search: dimensions beyond the register-resident query block use fp32
+    const bool pq = ix->pq_m != 0;  // lists of PQ codes: only the bf16 copy of the decoded rows exists, so bf16 it is
+    bool bf16 = (precision == NEEDLE_PRECISION_BF16 || pq) && flat_scan_bf16_dpad(ix->dim) != 0;
+    if (bf16 && choose_kprime((uint32_t)std::min<uint64_t>(k, ix->n), NEEDLE_PRECISION_BF16) > KPRIME_MAX) bf16 = false;
+    const uint32_t kprime = choose_kprime((uint32_t)std::min<uint64_t>(k, ix->n), bf16 ? NEEDLE_PRECISION_BF16 : NEEDLE_PRECISION_FP32);
+    const bool exact_only = precision == NEEDLE_PRECISION_EXACT_SCAN || kprime > KPRIME_MAX || (pq && !bf16);
+    if (exact_only) {
+        ST_TRY(ivf_probe_device(ix, d_queries, q, np, true));
+        ST_TRY(run_exact(ix, d_queries, nullptr, q, k, d_filter, d_out_ids, d_out_dists, d_out_counts, ix->v_probe32.as<uint32_t>(),
+                         ix->v_probe_n.as<uint32_t>(), np));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::lock_guard g(c->mu);
+        c->m.fallback_queries += q;
+        return NEEDLE_HIP_OK;
+    }
+    // The coarse step is enqueued and the search goes on behind it at once: whether the first-pass scores left some
+    // query's probe set open is read at the ONE synchronisation at the end (no device -> host copy between the probe and
+    // the merge); such queries -- none on typical data -- are then re-run with an exact coarse step.
+    ST_TRY(ivf_probe_device(ix, d_queries, q, np, true, /*defer=*/true));
+    needle_hip_index* cent = ix->centroids;
+    // the coarse step's query operand (bf16, unnormalised: both steps rank by Euclidean distance) serves the list scan too
+    const bool probe_bf16 = flat_scan_bf16_dpad(ix->dim) != 0 &&
+                            choose_kprime(std::min(np, ix->nlist), NEEDLE_PRECISION_BF16) <= (uint32_t)KPRIME_MAX;
+    const bool share = bf16 && probe_bf16 && cent->w_qop.p && cent->w_qn2.p && cent->w_qerr.p &&
+                       cent->dpad_bf16 == flat_scan_bf16_dpad(ix->dim);
+    uint32_t n_flagged = 0, n_probe_open = 0;
+    ST_TRY(ivf_scan_probed(ix, d_queries, q, k, np, bf16, d_filter, ix->v_probe32.as<uint32_t>(), ix->v_probe_n.as<uint32_t>(), d_out_ids,
+                           d_out_dists, d_out_counts, share ? cent->w_qop.p : nullptr, share ? cent->w_qn2.as<double>() : nullptr,
+                           share ? cent->w_qerr.as<float>() : nullptr, &n_flagged));
+    HIP_TRY(hipMemcpyAsync(&n_probe_open, cent->w_flagcnt.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->profiling) {
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
         std::lock_guard g(c->mu);
-        c->m.list_scans += 1;  // (the probe's own first pass over the centroids is counted under scan_launches)
+        c->m.list_scans += 1;  // (the probe's own first pass over the centroids is not timed separately)
         c->m.list_scan_ms_total += ms;
     }
     if (n_flagged > 0) {
         if (n_flagged > q) n_flagged = q;
-        ST_TRY(run_exact(ix, d_queries, pp.flagged, n_flagged, k, d_filter, d_out_ids, d_out_dists, d_out_counts, d_probe,
-                         d_probe_n, np));
+        ST_TRY(run_exact(ix, d_queries, ix->w_flagged.as<uint32_t>(), n_flagged, k, d_filter, d_out_ids, d_out_dists, d_out_counts,
+                         ix->v_probe32.as<uint32_t>(), ix->v_probe_n.as<uint32_t>(), np));
         HIP_TRY(hipStreamSynchronize(c->stream));
         std::lock_guard g(c->mu);
         c->m.fallback_queries += n_flagged;
+    }
+    if (n_probe_open > 0) {
+        // These queries were searched with a probe set the coarse step had not settled: settle it with the exact scan of the
+        // centroids, then search them again (gathered into a batch of their own) and put their answers in place.
+        if (n_probe_open > q) n_probe_open = q;
+        const uint32_t f = n_probe_open;
+        const uint32_t* d_sel = cent->w_flagged.as<uint32_t>();
+        ST_TRY(run_exact(cent, d_queries, d_sel, f, np, nullptr, ix->v_probe_ids.as<uint64_t>(), ix->v_probe_d.as<float>(),
+                         ix->v_probe_n.as<uint32_t>()));
+        const uint32_t total = q * np;
+        hipLaunchKernelGGL(ivf_narrow_probe_kernel, dim3((total + 255) / 256), dim3(256), 0, c->stream, ix->v_probe_ids.as<uint64_t>(), total,
+                           ix->v_probe32.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(ix->r_idx.ensure((size_t)f * sizeof(uint32_t)));
+        HIP_TRY(ix->r_q.ensure((size_t)f * ix->dim * sizeof(float)));
+        HIP_TRY(ix->r_ids.ensure((size_t)f * k * sizeof(uint64_t)));
+        HIP_TRY(ix->r_dists.ensure((size_t)f * k * sizeof(float)));
+        HIP_TRY(ix->r_cnt.ensure((size_t)f * sizeof(uint32_t)));
+        HIP_TRY(ix->v_probe_sel.ensure(((size_t)f * np + f) * sizeof(uint32_t)));
+        uint32_t* sel_probe = ix->v_probe_sel.as<uint32_t>();
+        uint32_t* sel_n = sel_probe + (size_t)f * np;
+        HIP_TRY(hipMemcpyAsync(ix->r_idx.p, d_sel, (size_t)f * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(launch_gather_rows(d_queries, ix->r_idx.as<uint32_t>(), f, ix->dim, ix->r_q.as<float>(), c->stream));
+        hipLaunchKernelGGL(ivf_gather_probe_kernel, dim3((f * np + 255) / 256), dim3(256), 0, c->stream, ix->r_idx.as<uint32_t>(), f, np,
+                           ix->v_probe32.as<uint32_t>(), ix->v_probe_n.as<uint32_t>(), sel_probe, sel_n);
+        HIP_TRY(hipGetLastError());
+        uint32_t again = 0;
+        ST_TRY(ivf_scan_probed(ix, ix->r_q.as<float>(), f, k, np, bf16, d_filter, sel_probe, sel_n, ix->r_ids.as<uint64_t>(),
+                               ix->r_dists.as<float>(), ix->r_cnt.as<uint32_t>(), nullptr, nullptr, nullptr, &again));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (again > 0) {
+            if (again > f) again = f;
+            ST_TRY(run_exact(ix, ix->r_q.as<float>(), ix->w_flagged.as<uint32_t>(), again, k, d_filter, ix->r_ids.as<uint64_t>(),
+                             ix->r_dists.as<float>(), ix->r_cnt.as<uint32_t>(), sel_probe, sel_n, np));
+        }
+        HIP_TRY(launch_scatter_results(ix->r_idx.as<uint32_t>(), f, k, ix->r_ids.as<uint64_t>(), ix->r_dists.as<float>(),
+                                       ix->r_cnt.as<uint32_t>(), d_out_ids, d_out_dists, d_out_counts, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::lock_guard g(c->mu);
+        c->m.refined_queries += f;
     }
     return NEEDLE_HIP_OK;
 }

@@ -748,7 +748,12 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams
         if (cls == 1) atomicAdd(&s_misc[3], 1u);
         __syncthreads();
         if (!ok) {  // block-uniform: the exact scan decides this query
-            if (j == 0) p.flagged[atomicAdd(p.flag_count, 1u)] = q;
+            if (j == 0) {
+                p.flagged[atomicAdd(p.flag_count, 1u)] = q;
+                // until then the query has no hits: a caller that goes on before the exact scan has run (the inverted-file
+                // search does not wait for its coarse step) must not take the unwritten slots for row ids
+                p.out_counts[q] = 0;
+            }
             return;
         }
         const uint32_t n_certain = s_misc[2], n_open = s_misc[3];

@@ -86,7 +86,13 @@ __global__ __launch_bounds__(256, 2) void flat_scan_f32_kernel(ScanParams p) {
     bool q_live = true;          // false: padding slot of an IVF item
     uint32_t qrow[4];            // query_op rows this thread stages (r = (tid + 256 i) >> 3)
     if (MODE == MODE_IVF) {
-        const IvfItem it = p.items[blockIdx.x];
+        // the grid is an upper bound sized on the host; the items this launch really has are counted on the device
+        uint32_t item_idx = blockIdx.x;
+        if (p.item_bounds) {
+            item_idx += p.item_bounds[0];
+            if (item_idx >= p.item_bounds[1]) return;  // workgroup-uniform, before any barrier
+        }
+        const IvfItem it = p.items[item_idx];
         t0 = it.tile0;
         t1 = it.tile1;
         const uint2* iq = p.item_queries + it.qoff;

@@ -162,7 +162,13 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 || (BF_FLAT_WG4X2 && KS32 <
     // staging rows and meeting the barriers, but leaves the matrix pipe to the wave it shares a SIMD with.
     bool wave_live = true;  // wave-uniform
     if (MODE == MODE_IVF) {
-        const IvfItem it = p.items[blockIdx.x];
+        // the grid is an upper bound sized on the host; the items this launch really has are counted on the device
+        uint32_t item_idx = blockIdx.x;
+        if (p.item_bounds) {
+            item_idx += p.item_bounds[0];
+            if (item_idx >= p.item_bounds[1]) return;  // workgroup-uniform, before any barrier
+        }
+        const IvfItem it = p.items[item_idx];
         wave_live = wave * QW < it.nq;
         tile_first = it.tile0;
         tile_mul = 1;

@@ -162,7 +162,7 @@ struct needle_hip_index {
     nh::DevBuf w_qerr;  // [q_pad] |query operand - its bf16 copy|
     nh::DevBuf r_idx, r_q, r_ids, r_dists, r_cnt;  // queries a reduced-precision pass could not decide, re-run in fp32
     nh::DevBuf x_keys, x_u32, x_u64, x_sel, x_mask;
-    nh::DevBuf v_probe_ids, v_probe_d, v_probe_n, v_probe32, v_items, v_itemq, v_lbase, v_regroup;
+    nh::DevBuf v_probe_ids, v_probe_d, v_probe_n, v_probe32, v_items, v_itemq, v_lbase, v_regroup, v_probe_sel;
     nh::DevBuf w_pqtab; // PQ table scan: interleaved distance tables of a chunk of queries
     nh::DevBuf b_work;  // binary scan: query codes, histograms, tie counts, collected keys
     // Re-entrant searches: every batch search runs on a search slot -- a view of this index (same resident data, its
@@ -202,10 +202,13 @@ private:
     needle_hip_status st_ = NEEDLE_HIP_OK;
 };
 void free_search_slots(needle_hip_index* ix);
-// flat search of one batch (api.hip); used by the IVF probe step as well
+// flat search of one batch (api.hip); used by the IVF probe step as well.  defer_flagged: return with the work enqueued and
+// without the host learning which queries the bound check left open: ix->w_flagcnt / w_flagged (device) name them, and
+// the caller owes them an answer
 needle_hip_status flat_search_batch_device(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k,
                                            int precision, const uint32_t* d_filter, uint64_t* d_out_ids,
-                                           float* d_out_dists, uint32_t* d_out_counts, bool set_only = false);
+                                           float* d_out_dists, uint32_t* d_out_counts, bool set_only = false,
+                                           bool defer_flagged = false);
 // exact scan of f_total slots; IVF: d_probe/d_probe_n name the lists each query may draw rows from
 needle_hip_status run_exact(needle_hip_index* ix, const float* d_queries, const uint32_t* d_qsel, uint32_t f_total,
                             uint32_t k, const uint32_t* d_filter, uint64_t* d_out_ids, float* d_out_dists,

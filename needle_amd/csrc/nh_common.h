@@ -136,6 +136,7 @@ struct ScanParams {
     // inverted-list scan: one workgroup per work item = (one list's row tiles) x (<= 128 of the
     // queries probing that list); rows are positions in the list-ordered copy of the base
     const IvfItem* items;     // [grid]
+    const uint32_t* item_bounds;  // device: this launch covers items [item_bounds[0], item_bounds[1]); null: items[0 .. grid)
     const uint2* item_queries;  // (query index, candidate list of the entry's first run; + IvfItem::list_add) per item entry
     const uint32_t* pos2id;   // [n_pad] original row id of a position, ~0 for padding
     uint32_t base_is_u8;      // base_op is a u8 code matrix (scalar-quantized scan)

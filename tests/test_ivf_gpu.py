@@ -270,7 +270,7 @@ def test_ivf_pq_lists(ctx, oracle, shape):
     ix.close()
 
 
-@pytest.mark.parametrize("case", ["duplicates", "near_ties", "nprobe_ge_nlist", "many_lists", "cluster40"])
+@pytest.mark.parametrize("case", ["duplicates", "near_ties", "nprobe_ge_nlist", "many_lists", "cluster40", "cluster200"])
 def test_probe_set_decided_by_scores(ctx, oracle, case):
     """The search needs the probed lists as a SET: centroids whose first-pass score decides their membership are not
     re-scored, the ones near the nprobe-th are (flat_post.hip, set-only re-score).  Centroid sets that put many
@@ -278,7 +278,8 @@ def test_probe_set_decided_by_scores(ctx, oracle, case):
     probes, and thousands of lists -- must give the oracle's hits all the same (ivf.rs:521-557)."""
     from needle_amd.ivf import IvfConfig, IvfIndex
 
-    rng = np.random.default_rng({"duplicates": 5, "near_ties": 6, "nprobe_ge_nlist": 7, "many_lists": 8, "cluster40": 9}[case])
+    rng = np.random.default_rng({"duplicates": 5, "near_ties": 6, "nprobe_ge_nlist": 7, "many_lists": 8, "cluster40": 9,
+                                 "cluster200": 10}[case])
     d = 64
     if case == "many_lists":
         n, nlist, nprobe = 40000, 1500, 24
@@ -291,6 +292,13 @@ def test_probe_set_decided_by_scores(ctx, oracle, case):
         # the re-score stages at a time, with the rest of the candidates clearly out
         n, nlist, nprobe = 20000, 96, 8
         near = rng.standard_normal((1, d)).astype(F) * (F(1.0) + F(2e-6) * rng.standard_normal((40, d)).astype(F))
+        cents = np.ascontiguousarray(np.concatenate([near, F(4.0) * rng.standard_normal((56, d)).astype(F)])[rng.permutation(nlist)])
+    elif case == "cluster200":
+        # 200 centroids within rounding of each other: more of them at the boundary than a query keeps candidates, so the
+        # first-pass scores cannot settle the probe set.  The search has gone on behind the coarse step by then (it does not
+        # wait for it): such queries are searched again behind an exact coarse step (metric: refined_queries).
+        n, nlist, nprobe = 20000, 256, 8
+        near = rng.standard_normal((1, d)).astype(F) * (F(1.0) + F(2e-6) * rng.standard_normal((200, d)).astype(F))
         cents = np.ascontiguousarray(np.concatenate([near, F(4.0) * rng.standard_normal((56, d)).astype(F)])[rng.permutation(nlist)])
     else:
         n, nlist, nprobe = 20000, 96, 8
@@ -310,6 +318,9 @@ def test_probe_set_decided_by_scores(ctx, oracle, case):
     probes = ix.probe(queries)
     for i in range(0, queries.shape[0], 7):
         assert np.array_equal(probes[i], oracle.ivf_probe(queries[i], cents, nprobe)), i
+    ctx.reset_metrics()
     for precision in ("bf16", "fp32"):
         _check_search(oracle, ix, base, cents, offsets, order, queries, nprobe, 10, precision=precision)
+    if case == "cluster200":
+        assert ctx.metrics()["refined_queries"] > 0
     ix.close()
