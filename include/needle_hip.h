@@ -158,7 +158,7 @@ needle_hip_status needle_hip_reset_metrics(needle_hip_ctx* ctx);
  * move plans and cost, never results.  Keys: "splits", "pre_tiles", "kseed",
  * "band", "stage0".."stage3" (percent of a slice per staged launch),
  * "no_dense", "no_set_only", "merge_keys", "merge_lists", "rs_cap", "rs_dc",
- * "ivf_no_seed", "ivf_seed_rows", "binary_two_scans", "debug" (bit 3: print what
+ * "ivf_no_seed", "ivf_seed_rows", "ivf_split", "binary_two_scans", "debug" (bit 3: print what
  * the first pass listed), "trace" and "poison" (process-wide), "reset" (back to
  * the built-in choices).  Unknown keys fail with
  * NEEDLE_HIP_ERR_INVALID_ARGUMENT. */

@@ -114,6 +114,23 @@ extern "C" needle_hip_status needle_hip_init(int device_id, needle_hip_ctx** out
     return NEEDLE_HIP_OK;
 }
 
+hipError_t nh::ensure_side_stream(needle_hip_ctx* c) {
+    if (c->side) return hipSuccess;
+    hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    if (e != hipSuccess) destroy_side_stream(c);
+    return e;
+}
+
+void nh::destroy_side_stream(needle_hip_ctx* c) {
+    if (c->side) (void)hipStreamSynchronize(c->side);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    c->side = nullptr; c->ev_fork = nullptr; c->ev_join = nullptr;
+}
+
 extern "C" void needle_hip_shutdown(needle_hip_ctx* c) {
     if (!c) return;
     std::vector<needle_hip_index*> bound;
@@ -126,6 +143,7 @@ extern "C" void needle_hip_shutdown(needle_hip_ctx* c) {
     for (needle_hip_index* ix : bound) nh::index_free(ix);  // (a nested centroid index may already be gone: no-op)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    destroy_side_stream(c);
     for (auto& b : c->scratch) b.release();
     for (int i = 0; i < 4; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -172,6 +190,7 @@ extern "C" needle_hip_status needle_hip_set_tuning(needle_hip_ctx* c, const char
     else if (k == "rs_dc") t.rs_dc = u;
     else if (k == "ivf_no_seed") t.ivf_no_seed = u;
     else if (k == "ivf_seed_rows") t.ivf_seed_rows = u;
+    else if (k == "ivf_split") t.ivf_split = u;
     else if (k == "binary_two_scans") t.binary_two_scans = u;
     else if (k == "trace") g_trace = u != 0;
     else if (k == "poison") g_poison = u != 0;
@@ -274,6 +293,7 @@ static SearchSlot* new_search_slot(const needle_hip_index* parent) {
 void nh::free_search_slots(needle_hip_index* ix) {
     for (SearchSlot* s : ix->slots) {
         (void)hipStreamSynchronize(s->ctx.stream);
+        destroy_side_stream(&s->ctx);
         release_workspace(&s->ix);
         release_workspace(&s->cent);
         for (auto& b : s->ctx.scratch) b.release();

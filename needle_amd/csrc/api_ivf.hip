@@ -604,9 +604,7 @@ static needle_hip_status ivf_scan_probed(needle_hip_index* ix, const float* d_qu
     // many workgroups instead of one long one; every (query, probed list, run) owns a candidate list of its own,
     // numbered consecutively per query: query i owns lists list_base[i] .. list_base[i+1]-1.  `run` doubles until the
     // lists of any query (bounded by the nprobe longest lists of the index) fit the merge kernel's bookkeeping.
-    // Thresholds start from a sample of every query's nearest list (ivf_seed_tau_kernel).  The probe slots are then
-    // scanned in up to three launches (by default slots 0-3, then the rest); after each launch a query's threshold
-    // is raised to the k-th best score it has listed, so the far lists only list what can still matter.
+    // Thresholds start from a sample of every query's nearest list (ivf_seed_tau_kernel).
     const bool dbg_t = (c->tune.debug & 8u) != 0;
     const uint32_t max_lists_per_query = std::max<uint32_t>(np, 2048);  // bounds the list bookkeeping, not correctness
     const uint32_t item_queries = bf16 ? flat_scan_bf16_ivf_queries_per_block(flat_scan_bf16_dpad(ix->dim)) : (uint32_t)TILE_QUERIES;
@@ -620,7 +618,10 @@ static needle_hip_status ivf_scan_probed(needle_hip_index* ix, const float* d_qu
     uint64_t runs_all = 0;  // runs of all lists together, and the most runs of one list
     const uint32_t max_runs = std::max<uint32_t>(1, (ix->list_tiles_desc.empty() ? 0u : ix->list_tiles_desc[0] + run - 1) / run);
     for (uint32_t t : ix->list_tiles_desc) runs_all += std::max<uint32_t>(1, (t + run - 1) / run);
-    uint32_t bounds[4] = {0, 0, std::min<uint32_t>(4, np), np};  // with seeded thresholds: slots 0-3, refresh, the rest
+    // One launch covers all probe slots (measured on 1.25M x 384, nlist 4096, nprobe 32, 10K queries: 1.35 ms per batch
+    // against 1.51 with slots 0-3 first and a threshold refresh behind them; every launch streams nearly all lists, and the
+    // refresh saves fewer listed rows than the second pass over the lists costs).  ivf_split = s < nprobe: slots [0, s) first.
+    uint32_t bounds[4] = {0, 0, std::min<uint32_t>(c->tune.ivf_split ? c->tune.ivf_split : np, np), np};
     // items of stage r: per (list, run) one item per item_queries pairs, rounded up once per (list, run) holding pairs
     uint64_t item_cap[3], items_cap = 0;
     for (int r = 0; r < 3; ++r) {
@@ -652,6 +653,12 @@ static needle_hip_status ivf_scan_probed(needle_hip_index* ix, const float* d_qu
     rg.b1 = bounds[1]; rg.b2 = bounds[2];
     rg.itemq = ix->v_itemq.as<uint2>();
     rg.items = ix->v_items.as<IvfItem>();
+    // Fork: the regrouping (four short kernels, one of them a single workgroup) stays on the search's stream; the query
+    // operand, the masked seeds and the threshold sample need only the probe lists and run beside it on the side stream.
+    HIP_TRY(ensure_side_stream(c));
+    HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     hipLaunchKernelGGL(ivf_regroup_count_kernel, dim3((q + 255) / 256), dim3(256), 0, c->stream, rg);
     hipLaunchKernelGGL(ivf_regroup_scan_kernel, dim3(1), dim3(1024), 0, c->stream, rg);
     hipLaunchKernelGGL(ivf_regroup_scatter_kernel, dim3((q * np + 255) / 256), dim3(256), 0, c->stream, rg);
@@ -675,13 +682,16 @@ static needle_hip_status ivf_scan_probed(needle_hip_index* ix, const float* d_qu
     HIP_TRY(ix->w_tau.ensure((size_t)q * sizeof(float)));
     HIP_TRY(ix->w_flagged.ensure((size_t)q * sizeof(uint32_t)));
     HIP_TRY(ix->w_flagcnt.ensure(sizeof(uint32_t)));
+    HIP_TRY(ix->w_tau0.ensure((size_t)q * sizeof(float)));
+    if (ix->d_valid || d_filter) HIP_TRY(ix->w_cinit.ensure((size_t)ix->n_pad * sizeof(float)));
     HIP_TRY(hipMemsetAsync(ix->w_lcnt.p, 0, (size_t)std::max<uint32_t>(total_lists, 1) * sizeof(uint32_t), c->stream));
     HIP_TRY(hipMemsetAsync(ix->w_flagcnt.p, 0, sizeof(uint32_t), c->stream));
+    // ---- side stream ----
     if (!shared) {
-        HIP_TRY(hipMemsetAsync(ix->w_qop.p, 0, (size_t)q * dpad * elt, c->stream));
+        HIP_TRY(hipMemsetAsync(ix->w_qop.p, 0, (size_t)q * dpad * elt, c->side));
         HIP_TRY(launch_row_prep(d_queries, q, ix->dim, dpad, false, bf16 ? nullptr : ix->w_qop.as<float>(),
                                 bf16 ? ix->w_qop.as<uint16_t>() : nullptr, nullptr, nullptr, ix->w_qn2.as<double>(), nullptr,
-                                bf16 ? ix->w_qerr.as<float>() : nullptr, nullptr, c->stream));
+                                bf16 ? ix->w_qerr.as<float>() : nullptr, nullptr, c->side));
     }
     const double* d_qn2 = shared ? shared_qn2 : ix->w_qn2.as<double>();
     const float* d_qerr = bf16 ? (shared ? shared_qerr : ix->w_qerr.as<float>()) : nullptr;
@@ -691,8 +701,7 @@ static needle_hip_status ivf_scan_probed(needle_hip_index* ix, const float* d_qu
     sp.query_op = shared ? shared_qop : ix->w_qop.p;
     sp.cinit = ix->d_cinit;
     if (ix->d_valid || d_filter) {
-        HIP_TRY(ix->w_cinit.ensure((size_t)ix->n_pad * sizeof(float)));
-        hipLaunchKernelGGL(ivf_masked_seed_kernel, dim3((ix->n_pad + 255) / 256), dim3(256), 0, c->stream, ix->d_cinit, ix->d_pos2id,
+        hipLaunchKernelGGL(ivf_masked_seed_kernel, dim3((ix->n_pad + 255) / 256), dim3(256), 0, c->side, ix->d_cinit, ix->d_pos2id,
                            ix->n_pad, ix->d_valid, d_filter, ix->w_cinit.as<float>());
         HIP_TRY(hipGetLastError());
         sp.cinit = ix->w_cinit.as<float>();
@@ -711,7 +720,6 @@ static needle_hip_status ivf_scan_probed(needle_hip_index* ix, const float* d_qu
     sp.pos2id = ix->d_pos2id;
     sp.n_queries = q;
     sp.kseed = std::min<uint32_t>(kprime, (uint32_t)std::min<uint64_t>(k, ix->n));  // rank k: the tightest threshold k sampled rows still reach
-    HIP_TRY(ix->w_tau0.ensure((size_t)q * sizeof(float)));
     sp.tau0 = ix->w_tau0.as<float>();
     TauBand band{};
     band.qn2 = d_qn2;
@@ -719,9 +727,8 @@ static needle_hip_status ivf_scan_probed(needle_hip_index* ix, const float* d_qu
     band.qerr = d_qerr;
     band.berr = ix->bf16_err;
     band.dim = ix->dim; band.metric = ix->metric; band.precision = scan_precision;
-    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     const bool no_seed = c->tune.ivf_no_seed != 0;  // tuning: thresholds start at -inf
-    if (no_seed) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ix->w_tau0.p, 0xff800000u, q, c->stream));
+    if (no_seed) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ix->w_tau0.p, 0xff800000u, q, c->side));
     if (!no_seed) {
         // rows sampled per query: fewer rows shorten this kernel (its scoring steps are serial) and weaken the thresholds
         // (more rows listed by the scans); measured on 1.25M x 384, nlist 4096, nprobe 32: 256 rows 2.34 ms per batch,
@@ -729,15 +736,18 @@ static needle_hip_status ivf_scan_probed(needle_hip_index* ix, const float* d_qu
         uint32_t sample_rows = 128;
         if (c->tune.ivf_seed_rows) sample_rows = std::min<uint32_t>(c->tune.ivf_seed_rows, IVF_SEED_ROWS);
         if (bf16)
-            hipLaunchKernelGGL(ivf_seed_tau_kernel<uint16_t>, dim3(q), dim3(256), 0, c->stream, d_queries, (const uint16_t*)ix->d_op_bf16,
+            hipLaunchKernelGGL(ivf_seed_tau_kernel<uint16_t>, dim3(q), dim3(256), 0, c->side, d_queries, (const uint16_t*)ix->d_op_bf16,
                                dpad, sample_rows, ix->d_cinit, d_probe, d_probe_n, np, ix->nlist, ix->d_list_pos, ix->d_list_len, ix->d_pos2id,
                                ix->d_valid, d_filter, ix->dim, sp.kseed, band, ix->w_tau0.as<float>());
         else
-            hipLaunchKernelGGL(ivf_seed_tau_kernel<float>, dim3(q), dim3(256), 0, c->stream, d_queries, (const float*)ix->d_raw, ix->dim,
+            hipLaunchKernelGGL(ivf_seed_tau_kernel<float>, dim3(q), dim3(256), 0, c->side, d_queries, (const float*)ix->d_raw, ix->dim,
                                sample_rows, ix->d_cinit, d_probe, d_probe_n, np, ix->nlist, ix->d_list_pos, ix->d_list_len, ix->d_pos2id,
                                ix->d_valid, d_filter, ix->dim, sp.kseed, band, ix->w_tau0.as<float>());
     }
     HIP_TRY(hipGetLastError());
+    // ---- join ----
+    HIP_TRY(hipEventRecord(c->ev_join, c->side));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     bool launched = false;
     for (int r = 0; r < 3; ++r) {
         if (item_cap[r] == 0) continue;

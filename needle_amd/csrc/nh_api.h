@@ -83,6 +83,7 @@ struct Tuning {
     uint32_t rs_cap = 0, rs_dc = 0;            // exact re-score: rows staged at a time / dimensions per block
     uint32_t ivf_no_seed = 0;    // inverted-list scan: thresholds start at -inf
     uint32_t ivf_seed_rows = 0;  // rows of the nearest list sampled per query for the starting threshold
+    uint32_t ivf_split = 0;      // probe slots scanned by the first list-scan launch (the threshold refresh follows it)
     uint32_t binary_two_scans = 0;  // binary codes: always the ranked two-scan path
 };
 
@@ -96,6 +97,10 @@ struct needle_hip_ctx {
     hipStream_t stream = nullptr;
     bool profiling = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // a second stream (created on first use) for work of one search that does not depend on what `stream` is doing:
+    // forked and joined with events, never synchronised on its own
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     needle_hip_metrics m{};
     nh::Tuning tune;
     std::recursive_mutex mu;  // recursive: a host-pointer operator holds it across staging, its _device form and the copy back
@@ -220,6 +225,8 @@ needle_hip_status ensure_bf16_copy(needle_hip_index* ix);
 // takes the device address of the static top-k workspace (ops.hip); the context's device must be current
 needle_hip_status topk_static_setup(needle_hip_ctx* c);
 needle_hip_index* index_new();  // registered as live; null when out of host memory
+hipError_t ensure_side_stream(needle_hip_ctx* c);
+void destroy_side_stream(needle_hip_ctx* c);
 void index_free(needle_hip_index* ix);
 needle_hip_status finish_operands(needle_hip_index* ix, bool validate);
 needle_hip_status upload_mask(needle_hip_index* ix, const uint32_t* mask_host);
