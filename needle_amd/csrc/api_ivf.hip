@@ -382,7 +382,7 @@ extern "C" needle_hip_status needle_hip_ivf_pq_build(needle_hip_ctx* c, const fl
     if (m == 0 || !codebooks || dim % m != 0)
         return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "need codebooks and dim (%u) divisible by the subvector count (%u)", dim, m);
     if (flat_scan_bf16_dpad(dim) == 0)
-        return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "IVF-PQ lists are scored through a bf16 copy of the decoded rows: at most 768 dimensions");
+        return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "IVF-PQ lists are scored through a bf16 copy of the decoded rows: at most 1536 dimensions");
     return ivf_build_impl(c, base, n, dim, centroids, nlist, assignment, valid_bitmask, m, codebooks, out);
 }
 

@@ -449,9 +449,12 @@ uint32_t flat_scan_bf16_dpad(uint32_t dim) {
     if (ks <= 24) return 384;
     if (ks <= 32) return 512;
     if (ks <= 48) return 768;
+    if (ks <= 64) return 1024;
+    if (ks <= 96) return 1536;
     return 0;
 }
-uint32_t flat_scan_bf16_queries_per_block(uint32_t dpad) { return dpad <= 384 ? 16u * BF_NTQ * BF_NW : 128u; }
+// (beyond 1024 dimensions a wave keeps one query tile: its stationary fragments alone fill 192 registers)
+uint32_t flat_scan_bf16_queries_per_block(uint32_t dpad) { return dpad <= 384 ? 16u * BF_NTQ * BF_NW : (dpad <= 1024 ? 128u : 64u); }
 #ifndef BF_IVF_WAVES
 #define BF_IVF_WAVES 4  // waves per workgroup of the inverted-list scan up to 384 dimensions: 128 query slots per work item, two
                         // items per CU (measured 2.5 % faster than 8 waves / 256 slots at nlist 4096, nprobe 32, 10K queries)
@@ -470,6 +473,8 @@ static hipError_t launch_bf16_mode(const ScanParams& p, hipStream_t stream) {
     case 384: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE, BF_NTQ, 12, CINIT, BF_NW>), grid, block, 0, stream, p); break;
     case 512: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE, 2, 16, CINIT, 4>), grid, block, 0, stream, p); break;
     case 768: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE, 2, 24, CINIT, 4>), grid, block, 0, stream, p); break;
+    case 1024: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE, 2, 32, CINIT, 4>), grid, block, 0, stream, p); break;
+    case 1536: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE, 1, 48, CINIT, 4>), grid, block, 0, stream, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -488,6 +493,8 @@ hipError_t launch_ivf_scan_bf16(const ScanParams& p, uint32_t n_items, hipStream
     case 384: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_IVF, 2, 12, true, BF_IVF_WAVES>), grid, block, 0, stream, p); break;
     case 512: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_IVF, 2, 16, true, 4>), grid, block, 0, stream, p); break;
     case 768: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_IVF, 2, 24, true, 4>), grid, block, 0, stream, p); break;
+    case 1024: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_IVF, 2, 32, true, 4>), grid, block, 0, stream, p); break;
+    case 1536: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_IVF, 1, 48, true, 4>), grid, block, 0, stream, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -504,6 +511,8 @@ static hipError_t launch_bf16_dense(const ScanParams& p, hipStream_t stream) {
     case 384: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_DENSE, BF_NTQ, 12, CINIT, BF_NW>), grid, block, 0, stream, p); break;
     case 512: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_DENSE, 2, 16, CINIT, 4>), grid, block, 0, stream, p); break;
     case 768: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_DENSE, 2, 24, CINIT, 4>), grid, block, 0, stream, p); break;
+    case 1024: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_DENSE, 2, 32, CINIT, 4>), grid, block, 0, stream, p); break;
+    case 1536: hipLaunchKernelGGL((flat_scan_bf16x_kernel<MODE_DENSE, 1, 48, CINIT, 4>), grid, block, 0, stream, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

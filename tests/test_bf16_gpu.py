@@ -42,10 +42,12 @@ def _check(oracle, got, base, queries, k, metric, valid=None, filt=None):
         assert np.all(ids[i, c:] == U64MAX) and np.all(np.isinf(dists[i, c:]))
 
 
-# every register-resident query layout: dpad 128, 256, 384 (two query tiles per wave), 512, 768 (one)
+# every register-resident query layout: dpad 128, 256, 384 (eight waves of two query tiles), 512, 768, 1024 (four waves
+# of two), 1536 (four waves of one)
 @pytest.mark.parametrize("metric", METRICS4)
 @pytest.mark.parametrize("shape", [(3000, 100, 130, 10), (517, 33, 3, 1), (9000, 200, 300, 10), (6000, 384, 270, 10),
-                                   (4000, 500, 140, 5), (3000, 768, 40, 10)])
+                                   (4000, 500, 140, 5), (3000, 768, 40, 10), (20000, 1024, 150, 10), (2500, 900, 70, 3),
+                                   (20000, 1536, 100, 10), (3000, 1300, 33, 10)])
 def test_bf16_shapes_all_metrics(ctx, oracle, metric, shape):
     import needle_amd as na
 

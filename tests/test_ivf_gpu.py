@@ -42,7 +42,8 @@ def _check_search(oracle, ix, base, cents, offsets, order, queries, nprobe, k, *
         assert np.array_equal(dists[i, :c].view(np.uint32), od[i, :c].view(np.uint32)), (i, dists[i, :c], od[i, :c])
 
 
-@pytest.mark.parametrize("shape", [(3000, 32, 16, 4, 10), (20000, 64, 64, 8, 10), (5000, 100, 40, 40, 5)])
+@pytest.mark.parametrize("shape", [(3000, 32, 16, 4, 10), (20000, 64, 64, 8, 10), (5000, 100, 40, 40, 5),
+                                   (4000, 1000, 24, 6, 10), (3000, 1536, 16, 5, 10)])  # (the last two: the widest bf16 list scans)
 def test_assignment_probe_and_search(ctx, oracle, shape):
     n, d, nlist, nprobe, k = shape
     base, cents, ix, assign, offsets, order = _setup(oracle, ctx, n, d, nlist, nprobe, seed=n)
