@@ -41,9 +41,26 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense, MI355X
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense
+BOOST_CLOCK_GHZ = 2.4           # the clock both peaks are quoted at
+KERNEL_SOURCES = {"flat_scan_bf16": ("flat_scan_bf16.hip", "nh_scan.h", "nh_select.h"),
+                  "flat_scan_f32": ("flat_scan.hip", "nh_scan.h", "nh_select.h")}
+
+
+def kernel_source_hash(kernel):
+    """sha256 over the sources of a first-pass kernel (what tools/summarize_prof.py stamps a counter record with)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    try:
+        for name in KERNEL_SOURCES[kernel]:
+            with open(os.path.join(ROOT, "needle_amd", "csrc", name), "rb") as fh:
+                h.update(fh.read())
+    except (OSError, KeyError):
+        return None
+    return h.hexdigest()
 GEN_CHUNK = 5000                # rows per generator stream; shard starts are multiples of it
 METRIC_LABEL = "batch-search QPS @ recall@10, 1M & 10M×384 cosine k=10, 1/2/4/8 MI355X"
-DEFAULT_PATHS = "flat10m,c5,ivf,sq8,pq,hnsw"
+DEFAULT_PATHS = "flat10m,c5,ivf,ivf_clustered,sq8,pq,hnsw"
 
 
 def parse(argv=None):
@@ -345,14 +362,22 @@ def run(args, be):
         achieved = flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
         peak = FP32_MFMA_PEAK_TFLOPS if prec == "fp32" else BF16_MFMA_PEAK_TFLOPS
         kernel = "flat_scan_" + ("f32" if prec == "fp32" else "bf16")
-        return {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": measured_traffic(kernel), "launch_ms": round(scan_ms, 3),
-                "launches_per_step": mm["scan_launches"] / max(mm["searches"], 1)}
+        rec = counter_record(kernel)
+        line = {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4),
+                "traffic": args.traffic_bytes if args.traffic_bytes is not None else (rec or {}).get("hbm_bytes_per_launch"),
+                "launch_ms": round(scan_ms, 3), "launches_per_step": mm["scan_launches"] / max(mm["searches"], 1)}
+        if rec and rec.get("held_clock_ghz"):
+            # `peak` is priced at the 2.4 GHz boost clock; under this kernel the chip held `held_clock_ghz` (counter pass:
+            # GRBM_GUI_ACTIVE / 8 / kernel time), so the MFMA pipes could have delivered peak * held / 2.4 at most
+            line["held_clock_ghz"] = rec["held_clock_ghz"]
+            line["frac_of_peak_at_held_clock"] = round(achieved / (peak * rec["held_clock_ghz"] / BOOST_CLOCK_GHZ), 4)
+        return line
 
-    def measured_traffic(kernel):
-        """HBM bytes per launch from a separate rocprofv3 --pmc pass over this same workload, if recorded."""
-        if args.traffic_bytes is not None:
-            return args.traffic_bytes
+    def counter_record(kernel):
+        """What a separate rocprofv3 --pmc pass over this same workload recorded for `kernel` (HBM bytes per search,
+        the clock held), or None: when no pass was recorded, the workload differs, or the kernel's sources changed
+        since (the record carries their hash)."""
         try:
             with open(os.path.join(ROOT, "needle_amd", "measured_traffic.json")) as fh:
                 rec = json.load(fh).get(kernel)
@@ -361,7 +386,9 @@ def run(args, be):
         want = {"rows": hi - lo, "dim": args.dim, "queries": args.queries, "k": args.k, "metric": args.metric}
         if not rec or any(rec.get("workload", {}).get(key) != val for key, val in want.items()):
             return None
-        return rec["hbm_bytes_per_launch"]
+        if rec.get("source_sha256") != kernel_source_hash(kernel):
+            return None
+        return rec
 
     elapsed, m, out = timed(args.precision, args.steps, args.warmup)
     ids, dists, counts = out

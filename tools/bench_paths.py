@@ -5,6 +5,7 @@ the configurations BASELINE.json lists (one JSON line per path):
   c1   exact flat, 100K x 128 L2, 1K queries, k=10                      (plumbing shape)
   c5   exact flat, 1M x 768 dot product, 10 % filter bitmask, k=100, 1K queries
   ivf  IVF-Flat nlist=4096 nprobe=32 over 1.25M x 384 (= 10M / 8 GPUs), 10K queries, k=10
+  ivf_clustered  the same over a mixture of 4096 Gaussians (recall@10 is meaningful there)
   sq8  SQ8 asymmetric scan over 6.25M x 384 codes (= 50M / 8), 1K queries, k=10
   pq   PQ m=48 table scan over 6.25M x 48 codes (= 50M / 8), 1K queries, k=10
   binary  1-bit codes, Hamming scan over 6.25M x 384 bits (= 50M / 8), 1K queries, k=10
@@ -212,17 +213,27 @@ def trained_centroids(ctx, sample, nlist, iters, seed=11):
     return ix.centroids, time.perf_counter() - t0
 
 
-def ivf_case(ctx, dev, n, dim, nlist, nprobe, nq, k, steps, oracle=None, centroids="trained", normalise=True):
+def ivf_case(ctx, dev, n, dim, nlist, nprobe, nq, k, steps, oracle=None, centroids="trained", normalise=True, data="gaussian"):
+    """data = "gaussian": i.i.d. rows (no cluster structure: recall@10 of ANY inverted file is then a few percent);
+    "clustered": a mixture of `nlist` Gaussians (centres N(0, 1), spread 0.5 per component), the structure embeddings
+    have -- recall@10 against the exact search says something there.  Same seeds in both modes."""
     rng = np.random.default_rng(11)
     base = rng.standard_normal((n, dim), dtype=F)
+    queries = rng.standard_normal((nq, dim), dtype=F)
+    if data == "clustered":
+        crng = np.random.default_rng(12)
+        centres = crng.standard_normal((nlist, dim), dtype=F)
+        base *= F(0.5)
+        queries *= F(0.5)
+        for s0 in range(0, n, 1 << 18):  # in pieces: the gathered centres of 1.25M rows are 1.9 GB
+            base[s0:s0 + (1 << 18)] += centres[crng.integers(0, nlist, min(1 << 18, n - s0))]
+        queries += centres[crng.integers(0, nlist, nq)]
     if normalise:  # the configuration's "cosine": IvfIndex ranks by Euclidean distance (ivf.rs:67), over unit rows the same order
         base = ctx.normalize(base)
+        queries = ctx.normalize(queries)
     cents, train_s = np.ascontiguousarray(base[rng.choice(n, nlist, replace=False)]), 0.0
     if centroids == "trained":  # k-means on a sample of 100 rows per list, as an index is trained
         cents, train_s = trained_centroids(ctx, base[rng.choice(n, min(n, 100 * nlist), replace=False)], nlist, 8)
-    queries = rng.standard_normal((nq, dim), dtype=F)
-    if normalise:
-        queries = ctx.normalize(queries)
     h = C.c_void_p()
     t0 = time.perf_counter()
     _lib.check(_lib.lib().needle_hip_ivf_build(ctx._h, base.ctypes.data, n, dim, cents.ctypes.data, nlist, None, None,
@@ -247,9 +258,22 @@ def ivf_case(ctx, dev, n, dim, nlist, nprobe, nq, k, steps, oracle=None, centroi
     bytes_items = int((((per_list + 127) // 128) * padded).sum()) * row_bytes      # what the list-major scan reads
     bytes_once = int(padded[per_list > 0].sum()) * row_bytes                         # every probed list once
     bytes_unbatched = int((per_list * sizes.astype(np.int64)).sum()) * row_bytes     # per-query scans, as the reference
+    bytes_once_rows = int(sizes.astype(np.int64)[per_list > 0].sum()) * row_bytes   # every probed list once, its rows only: <= 4*N*D
     pairs = int((per_list * sizes.astype(np.int64)).sum())
+    # recall@10 against the exact flat search of the same rows (the library's own, checked against the oracle elsewhere)
+    flat = na.FlatIndex(ctx, base, na.DistanceFunction.Euclidean)
+    exact = search_device(flat._h, dq, k, precision="bf16")[0].cpu().numpy()
+    flat.close()
+    got_ids = out[0].cpu().numpy()
+
+    def recall_of(found, truth):
+        return float(np.mean([len(np.intersect1d(found[i], truth[i])) / max(1, truth.shape[1]) for i in range(found.shape[0])]))
+
+    recall_all = recall_of(got_ids, exact)
     bytes_bf16 = bytes_items // 2  # what the bf16 list scan streams (2 bytes per value)
-    extra = {"centroids": centroids, "rows": "unit-normalised Gaussian" if normalise else "Gaussian", "largest_list": int(sizes.max()), "list_scan": "bf16",
+    rows_label = ("unit-normalised " if normalise else "") + ("mixture of %d Gaussians" % nlist if data == "clustered" else "Gaussian")
+    extra = {"centroids": centroids, "rows": rows_label, "largest_list": int(sizes.max()), "list_scan": "bf16",
+             "recall_at_10": round(recall_all, 4),
              "list_scan_ms": round(list_scan_ms, 3),
              "list_scan_only_GBps_f32_rows": round(bytes_items / list_scan_ms / 1e6, 1) if list_scan_ms > 0 else None,
              "list_scan_only_GBps_bf16_streamed": round(bytes_bf16 / list_scan_ms / 1e6, 1) if list_scan_ms > 0 else None,
@@ -260,7 +284,9 @@ def ivf_case(ctx, dev, n, dim, nlist, nprobe, nq, k, steps, oracle=None, centroi
                                         if CONCURRENCY else None),
              "fp32_list_scan_ms_per_batch": round(sec32 * 1e3, 3), "build_s": round(build_s, 2), "train_s": round(train_s, 2),
              "scanned_pairs": pairs,
-             "bytes_listmajor": bytes_items, "bytes_each_probed_list_once": bytes_once, "bytes_unbatched": bytes_unbatched,
+             "bytes_listmajor": bytes_items, "bytes_each_probed_list_once": bytes_once_rows,
+             "bytes_each_probed_list_once_with_tile_padding": bytes_once, "bytes_unbatched": bytes_unbatched,
+             "frac_of_hbm_peak_each_probed_list_once": round(bytes_once_rows / sec / 1e9 / HBM_PEAK_GBS, 4),
              "listmajor_GBps_over_whole_search": round(bytes_items / sec / 1e9, 1),
              "frac_of_hbm_peak": round(bytes_items / sec / 1e9 / HBM_PEAK_GBS, 4),
              "pair_gflops_over_whole_search": round(2.0 * pairs * dim / sec / 1e9, 1)}
@@ -278,8 +304,12 @@ def ivf_case(ctx, dev, n, dim, nlist, nprobe, nq, k, steps, oracle=None, centroi
         extra["parity"] = {"queries_checked": s, "assignment_from": "oracle" if small else "device (tested against the oracle)",
                            "ids_equal": bool(np.array_equal(gi, oi)),
                            "dists_bit_equal": bool(np.array_equal(bits(out[1][:s].cpu().numpy()), bits(od))),
-                           "probe_lists_equal": bool(np.array_equal(probe[:s].astype(np.int64), op.astype(np.int64)))}
-    emit("ivf", f"IVF-Flat nlist={nlist} nprobe={nprobe} over {n}x{dim} Euclidean, k={k}", nq, sec, extra)
+                           "probe_lists_equal": bool(np.array_equal(probe[:s].astype(np.int64), op.astype(np.int64))),
+                           # the same queries' recall from the oracle's inverted file and from the library's: equal by construction
+                           "recall_at_10_oracle_ivf": round(recall_of(oi.astype(np.int64), exact[:s]), 4),
+                           "recall_at_10_library_ivf": round(recall_of(got_ids[:s], exact[:s]), 4)}
+    emit("ivf" if data == "gaussian" else "ivf_" + data, f"IVF-Flat nlist={nlist} nprobe={nprobe} over {n}x{dim} Euclidean ({rows_label} rows), k={k}",
+         nq, sec, extra)
     _lib.lib().needle_hip_index_destroy(h)
 
 
@@ -348,6 +378,8 @@ def pq_case(ctx, dev, n, dim, m_sub, nq, k, steps, oracle=None, build_timing=Tru
             byts = (-(-nq // 256)) * n * dim * 2
             extra = {"first_pass": "bf16 decoded rows on the matrix cores, table arithmetic for the candidates",
                      "scan_ms": round(scan_ms, 3), "bytes_scanned": byts, "scan_GBps": round(byts / scan_ms / 1e6, 1),
+                     "code_bytes_per_row": m_sub, "decoded_row_bytes": 2 * dim,
+                     "hbm_held_by_the_decoded_copy_GB": round(n * dim * 2 / 1e9, 2),
                      "frac_of_hbm_peak": round(byts / scan_ms / 1e6 / HBM_PEAK_GBS, 4),
                      "scan_tflops": round(2.0 * nq * n * dim / scan_ms / 1e9, 1),
                      "roofline": roofline("hbm", (-(-nq // 256)) * n * m_sub / scan_ms / 1e6, "GB/s", "pq: bf16 scan of the decoded rows",
@@ -492,6 +524,8 @@ def run_paths(ctx, dev, want, steps=2, oracle=None, scale=1.0, hnsw_rows=8192, c
                       oracle=oracle, precisions=("bf16",), parity_queries=16)
         if "ivf" in want:
             ivf_case(ctx, dev, int(1_250_000 * sc), 384, max(16, int(4096 * sc)), 32, 10_000, 10, steps, oracle=oracle)
+        if "ivf_clustered" in want:
+            ivf_case(ctx, dev, int(1_250_000 * sc), 384, max(16, int(4096 * sc)), 32, 10_000, 10, steps, oracle=oracle, data="clustered")
         if "sq8" in want:
             sq8_case(ctx, dev, int(6_250_000 * sc), 384, 1000, 10, steps, oracle=oracle)
         if "pq" in want:
@@ -538,6 +572,9 @@ def main():
     if "ivf" in want:
         ivf_case(ctx, dev, int(1_250_000 * sc), 384, max(16, int(4096 * sc)), 32, 10_000, 10, args.steps, oracle=oracle,
                  centroids=args.ivf_centroids)
+    if "ivf_clustered" in want:
+        ivf_case(ctx, dev, int(1_250_000 * sc), 384, max(16, int(4096 * sc)), 32, 10_000, 10, args.steps, oracle=oracle,
+                 centroids=args.ivf_centroids, data="clustered")
     if "sq8" in want:
         sq8_case(ctx, dev, int(6_250_000 * sc), 384, 1000, 10, args.steps, oracle=oracle)
     if "pq" in want:

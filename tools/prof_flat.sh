@@ -14,5 +14,5 @@ timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format c
     python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 --paths none "$@" > "$OUT/pmc_fetch.log" 2>&1 || { echo "pmc fetch failed"; tail -5 "$OUT/pmc_fetch.log"; exit 1; }
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_write" -- \
     python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 --paths none "$@" > "$OUT/pmc_write.log" 2>&1 || { echo "pmc write failed"; tail -5 "$OUT/pmc_write.log"; exit 1; }
-python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+python3 tools/summarize_prof.py "$OUT" ${WRITE_TRAFFIC:+--write-traffic} > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
