@@ -72,20 +72,52 @@ __global__ __launch_bounds__(64) void merge_select_kernel(PostParams p, uint32_t
         }
         if (lane == 0) loff[n_lists] = total;
         __syncthreads();
-        if (total <= MERGE_KEYS) {
-            for (uint32_t e = lane; e < total; e += 64) {
-                uint32_t lo = 0, hi = n_lists;  // largest list index with loff <= e
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (loff[mid] <= e) lo = mid; else hi = mid;
+        // The concatenation is taken MERGE_KEYS entries at a time (usually all of it at once); between two pieces the
+        // buffer is cut down to its kprime best.  Four entries per lane and step: their lists are found first, then
+        // their loads are in flight together.
+        const uint32_t all = total;
+        uint32_t kept = 0;
+        for (uint32_t e0 = 0; e0 < all;) {
+            const uint32_t chunk = min(all - e0, MERGE_KEYS - kept);
+            for (uint32_t e = lane; e < chunk; e += 256) {
+                uint2 v[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) {
+                    const uint32_t g = e0 + e + 64u * u;
+                    v[u] = make_uint2(0u, 0u);
+                    if (e + 64u * u < chunk) {
+                        uint32_t lo = 0, hi = n_lists;  // largest list index with loff <= g
+                        while (hi - lo > 1) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (loff[mid] <= g) lo = mid; else hi = mid;
+                        }
+                        v[u] = p.lists[(first + lo) * p.cap + (g - loff[lo])];
+                    }
                 }
-                const uint2 v = p.lists[(first + lo) * p.cap + (e - loff[lo])];
-                mkeys[e] = cand_key(v.x, v.y);
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u)
+                    if (e + 64u * u < chunk) mkeys[kept + e + 64u * u] = cand_key(v[u].x, v[u].y);
             }
-            done = true;
-        } else {
-            total = 0;
+            kept += chunk;
+            e0 += chunk;
+            if (e0 < all) {  // wave-uniform; the buffer is full (kept == MERGE_KEYS > kprime)
+                __syncthreads();
+                const uint64_t kth = wave_kth_largest_lds<PER>(mkeys, kept, p.kprime, lane);
+                uint32_t base = 0;
+                for (uint32_t i = 0; i < kept; i += 64) {  // in-place: a chunk is read whole before any of its slots is written
+                    const uint64_t key = (i + lane < kept) ? mkeys[i + lane] : 0ull;
+                    const bool keep = (i + lane < kept) && key >= kth;
+                    const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+                    __syncthreads();
+                    if (keep) mkeys[base + __builtin_popcountll(m & lt_mask)] = key;
+                    base += __builtin_popcountll(m);
+                    __syncthreads();
+                }
+                kept = base;  // == kprime: the keys are distinct
+            }
         }
+        total = kept;
+        done = true;
     }
     // lists per group: their entries (<= kprime each) fit beside kprime kept keys
     const uint32_t group = min(64u, max(1u, (MERGE_KEYS - p.kprime) / p.kprime));
@@ -180,6 +212,7 @@ hipError_t launch_merge_select(const PostParams& p, hipStream_t stream) {
 // ---------------------------------------------------------------------------
 constexpr uint32_t DS_SURV = 1024;  // survivors the narrowed selection holds
 constexpr int DS_T = (KPRIME_MAX + 63) / 64;
+constexpr int DS_HELD = 16;         // steps of 256 scores a wave keeps in registers between its two sweeps
 
 // kprime-th largest of ord[0 .. total) bit by bit (total >= kprime); zeros sort below every live score
 __device__ inline uint32_t wave_kth_largest_u32(const uint32_t* ord, uint32_t total, uint32_t kprime, uint32_t lane) {
@@ -248,20 +281,39 @@ __global__ __launch_bounds__(64) void dense_select_kernel(PostParams p) {
     // waiting on memory 64 times over)
     const uint32_t nq4 = (p.n + 3u) & ~3u;  // <= dense_ld: the matrix rows are padded to whole 128-row tiles
     const bool masked = p.valid != nullptr || p.filter != nullptr;
+    // A row of up to DS_HELD * 256 scores is read from memory ONCE: all its loads are issued together and the lane's
+    // 4 * DS_HELD values stay in registers for the second sweep (a wave is otherwise a chain of memory latencies: one
+    // per step of either sweep).
+    uint32_t held[DS_HELD][4];
+    const bool in_regs = nq4 <= (uint32_t)DS_HELD * 256u;  // wave-uniform
+    auto offer = [&](uint32_t o) {
+        live += o != 0u ? 1u : 0u;
+#pragma unroll
+        for (int t = 0; t < DS_T; ++t) {  // insertion: o sinks to its place, the smallest falls out
+            const uint32_t hi = max(top[t], o);
+            o = min(top[t], o);
+            top[t] = hi;
+        }
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < DS_HELD; ++u) {
+            const uint32_t i = (uint32_t)u * 256u + lane * 4u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) held[u][j] = 0u;
+            if (i < nq4) dense_ord4(p, sc, i, masked, held[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < DS_HELD; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) offer(held[u][j]);
+    } else {
 #pragma unroll 4
-    for (uint32_t i = lane * 4; i < nq4; i += 256) {
-        uint32_t o4[4];
-        dense_ord4(p, sc, i, masked, o4);
+        for (uint32_t i = lane * 4; i < nq4; i += 256) {
+            uint32_t o4[4];
+            dense_ord4(p, sc, i, masked, o4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            live += o4[j] != 0u ? 1u : 0u;
-            uint32_t o = o4[j];
-#pragma unroll
-            for (int t = 0; t < DS_T; ++t) {  // insertion: o sinks to its place, the smallest falls out
-                const uint32_t hi = max(top[t], o);
-                o = min(top[t], o);
-                top[t] = hi;
-            }
+            for (int j = 0; j < 4; ++j) offer(o4[j]);
         }
     }
 #pragma unroll
@@ -282,10 +334,7 @@ __global__ __launch_bounds__(64) void dense_select_kernel(PostParams p) {
     // second sweep: the rows at or above the pivot (all live rows when there is none), compacted in sweep order
     const uint32_t floor_ord = max(pivot, 1u);
     uint32_t surv = 0;
-    for (uint32_t i0 = 0; i0 < nq4; i0 += 256) {  // every lane takes every step: the ballots below count whole waves
-        const uint32_t i = i0 + lane * 4;
-        uint32_t o4[4] = {0u, 0u, 0u, 0u};
-        if (i < nq4) dense_ord4(p, sc, i, masked, o4);
+    auto sweep4 = [&](const uint32_t (&o4)[4], uint32_t i) {  // every lane takes every step: the ballots count whole waves
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool keep = o4[j] >= floor_ord;
@@ -293,6 +342,18 @@ __global__ __launch_bounds__(64) void dense_select_kernel(PostParams p) {
             const uint32_t pos = surv + __builtin_popcountll(m & lt_mask);
             if (keep && pos < DS_SURV) { s_ord[pos] = o4[j]; s_row[pos] = i + j; }
             surv += __builtin_popcountll(m);
+        }
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < DS_HELD; ++u)
+            if ((uint32_t)u * 256u < nq4) sweep4(held[u], (uint32_t)u * 256u + lane * 4u);
+    } else {
+        for (uint32_t i0 = 0; i0 < nq4; i0 += 256) {
+            const uint32_t i = i0 + lane * 4;
+            uint32_t o4[4] = {0u, 0u, 0u, 0u};
+            if (i < nq4) dense_ord4(p, sc, i, masked, o4);
+            sweep4(o4, i);
         }
     }
     if (live <= p.kprime && surv <= DS_SURV) {  // every live row is a candidate (kprime <= KPRIME_MAX < DS_SURV)
