@@ -69,8 +69,8 @@ typedef enum needle_metric {
     NEEDLE_METRIC_CHEBYSHEV = 6
 } needle_metric;
 
-/* Which of the reference's two scalar arithmetics the reported distances
- * (and therefore the ranking) reproduce bit for bit:
+/* Which of the reference's arithmetics the reported distances (and therefore
+ * the ranking) reproduce bit for bit:
  *   DISTANCE_RS : src/distance.rs:153-316 sequential sums -- what
  *                 Collection::search / batch_search / compute_ground_truth use
  *   ACCEL_CHUNK4: src/experimental/gpu/common.rs:515-581 groups of four --
@@ -80,11 +80,19 @@ typedef enum needle_metric {
  *                 service's kernels -- cosine as one loop over three sums from
  *                 +0.0 with `denominator < f32::EPSILON -> 1.0`; euclidean and
  *                 dot product as DISTANCE_RS.  Operator-level calls only
- *                 (batch_distance, distance_matrix, multi_query_search). */
+ *                 (batch_distance, distance_matrix, multi_query_search).
+ *   AVX2        : src/distance.rs:481-591, what DISTANCE_RS's functions compute
+ *                 in a reference BUILT WITH AVX2 ENABLED (-C target-cpu=native):
+ *                 eight lane sums of fused multiply-adds, folded as hsum_avx
+ *                 (:489-496), the len % 8 tail added after the fold.  Cosine,
+ *                 cosine-normalized, euclidean, dot product and manhattan
+ *                 differ from DISTANCE_RS; hamming and chebyshev do not.  Flat
+ *                 indexes, normalize and the operator-level calls. */
 typedef enum needle_arith {
     NEEDLE_ARITH_DISTANCE_RS = 0,
     NEEDLE_ARITH_ACCEL_CHUNK4 = 1,
-    NEEDLE_ARITH_SERVICE = 2
+    NEEDLE_ARITH_SERVICE = 2,
+    NEEDLE_ARITH_AVX2 = 3
 } needle_arith;
 
 /* Arithmetic of the candidate-generating first pass.  The returned ids and

@@ -750,7 +750,9 @@ __device__ inline double set_margin(const TauBand& band, uint32_t q) {
     return 2.0 * band_eps(band, q) + 2.05 * gam * s * s;
 }
 
-template <bool SET_ONLY>
+// AVX: the distances follow the order of a reference build with AVX2 enabled (exact_avx2: eight lane sums per
+// accumulator, kept across the dimension blocks; dc is then a multiple of 8).
+template <bool SET_ONLY, bool AVX = false>
 __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams p, uint32_t dc, uint32_t rcap, TauBand band) {
     extern __shared__ __attribute__((aligned(16))) float stage[];  // [dc] query block, then [rcap][dc + 4] row blocks
     __shared__ uint64_t skey[KPRIME_MAX];
@@ -855,6 +857,8 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams
         RefAcc acc;
         const float zero = p.arith == NEEDLE_ARITH_ACCEL_CHUNK4 ? 0.0f : -0.0f;  // Rust's f32 Sum folds from -0.0
         acc.a = zero; acc.b = zero; acc.c = zero;
+        AvxAcc va, vq, vb;  // AVX: q.b (or the differences), q.q, b.b
+        if (AVX) { avx_init(va); avx_init(vq); avx_init(vb); }
         float* qs = stage;
         float* rows = stage + dc;
         const uint32_t ld = dc + 4;  // rows 16-byte aligned, 4 banks apart: the 16-byte reads of thread j's walk over row j are conflict free
@@ -890,7 +894,18 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams
                 }
             }
             __syncthreads();
-            if (j >= g0 && j < g0 + gn) {
+            if (AVX) {
+                if (j >= g0 && j < g0 + gn) {
+                    const float* bs = rows + (j - g0) * ld;
+                    if (p.metric == NEEDLE_METRIC_EUCLIDEAN) avx_accumulate<AVX_L2>(va, qs, bs, c0, c0 + len, p.dim);
+                    else if (p.metric == NEEDLE_METRIC_MANHATTAN) avx_accumulate<AVX_L1>(va, qs, bs, c0, c0 + len, p.dim);
+                    else avx_accumulate<AVX_DOT>(va, qs, bs, c0, c0 + len, p.dim);
+                    if (p.metric == NEEDLE_METRIC_COSINE) {
+                        avx_accumulate<AVX_DOT>(vq, qs, qs, c0, c0 + len, p.dim);
+                        avx_accumulate<AVX_DOT>(vb, bs, bs, c0, c0 + len, p.dim);
+                    }
+                }
+            } else if (j >= g0 && j < g0 + gn) {
                 const float* bs = rows + (j - g0) * ld;
                 switch (kind) {
                 case RK_RS_COS: ref_accumulate_staged<RK_RS_COS>(acc, qs, bs, c0, c0 + len, p.dim); break;
@@ -907,6 +922,7 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams
             float v = ref_finish(kind, acc);
             if (kind == RK_RS_DOT || kind == RK_C4_DOT)
                 v = p.metric == NEEDLE_METRIC_COSINE_NORMALIZED ? 1.0f - v : -v;
+            if (AVX) v = avx2_distance(p.metric, avx_finish(va, p.dim), avx_finish(vq, p.dim), avx_finish(vb, p.dim));
             d = canon_distance(v);
         }
     }
@@ -946,7 +962,8 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams
 
 hipError_t launch_rescore_finalize(const PostParams& p, hipStream_t stream, const TauBand* set_only_band) {
     if (p.q == 0) return hipSuccess;
-    if (set_only_band && (p.metric != NEEDLE_METRIC_EUCLIDEAN || !p.cand_scores || p.sq_codes || p.pq_codes || p.pos2id))
+    if (set_only_band && (p.metric != NEEDLE_METRIC_EUCLIDEAN || !p.cand_scores || p.sq_codes || p.pq_codes || p.pos2id ||
+                          p.arith == NEEDLE_ARITH_AVX2))
         return hipErrorInvalidValue;
     // Rows staged at a time (rcap) and block of dimensions per stage (dc, a multiple of 4: groups of four never straddle
     // blocks).  A workgroup is a chain of dependent gathers, so what counts is how many of them a CU holds: the image is
@@ -956,8 +973,12 @@ hipError_t launch_rescore_finalize(const PostParams& p, hipStream_t stream, cons
     uint32_t dc = set_only_band ? 128u : 64u;
     if (p.tune_rs_cap >= 4 && p.tune_rs_cap <= p.kprime) rcap = p.tune_rs_cap;  // planning overrides
     if (p.tune_rs_dc / 4 * 4 >= 4 && p.tune_rs_dc <= 128) dc = p.tune_rs_dc / 4 * 4;
+    const bool avx = p.arith == NEEDLE_ARITH_AVX2 && !p.sq_codes && !p.pq_codes && avx2_metric(p.metric);
+    if (avx) dc = std::max<uint32_t>(8u, dc / 8 * 8);  // whole groups of eight lanes per block
     const size_t lds = ((size_t)dc + (size_t)rcap * (dc + 4)) * sizeof(float);
-    if (set_only_band)
+    if (avx && !set_only_band)
+        hipLaunchKernelGGL((rescore_finalize_kernel<false, true>), dim3(p.q), dim3(RS_THREADS), lds, stream, p, dc, rcap, TauBand{});
+    else if (set_only_band)
         hipLaunchKernelGGL(rescore_finalize_kernel<true>, dim3(p.q), dim3(RS_THREADS), lds, stream, p, dc, rcap, *set_only_band);
     else
         hipLaunchKernelGGL(rescore_finalize_kernel<false>, dim3(p.q), dim3(RS_THREADS), lds, stream, p, dc, rcap, TauBand{});
@@ -1053,7 +1074,15 @@ __global__ __launch_bounds__(EX_ROWS) void exact_keys_kernel(ExactParams p) {
     for (int s = 0; s < EX_SLOTS; ++s) { acc[s].a = zero; acc[s].b = kind == RK_PQ_TABLE ? -0.0f : zero; acc[s].c = zero; }
 
     const uint32_t rows_here = min((uint32_t)EX_ROWS, p.n > row0 ? p.n - row0 : 0u);
-    for (uint32_t c0 = 0; c0 < p.dim; c0 += EX_DC) {
+    // the AVX2-build order (eight lane sums per accumulator) is not staged: every thread walks its own row
+    const bool avx = p.arith == NEEDLE_ARITH_AVX2 && !sq8 && !pq && avx2_metric(p.metric);  // uniform over the grid
+    float avx_d[EX_SLOTS];
+    if (avx) {
+#pragma unroll
+        for (int s = 0; s < EX_SLOTS; ++s)
+            avx_d[s] = live[s] ? exact_avx2(p.metric, p.query_raw + (uint64_t)qidx[s] * p.dim, p.base_raw + (uint64_t)i * p.dim, p.dim) : 0.0f;
+    }
+    for (uint32_t c0 = 0; !avx && c0 < p.dim; c0 += EX_DC) {
         const uint32_t len = min((uint32_t)EX_DC, p.dim - c0);
         __syncthreads();
         if (t < EX_SLOTS * EX_DC) {
@@ -1100,6 +1129,7 @@ __global__ __launch_bounds__(EX_ROWS) void exact_keys_kernel(ExactParams p) {
         if (live[s]) {
             float v = ref_finish(kind, acc[s]);
             if (kind == RK_RS_DOT || kind == RK_C4_DOT) v = p.metric == NEEDLE_METRIC_COSINE_NORMALIZED ? 1.0f - v : -v;
+            if (avx) v = avx_d[s];
             key = hit_key(canon_distance(v), id);
         }
         if (i < p.n) p.keys[(uint64_t)f * p.n + i] = key;
@@ -1334,6 +1364,15 @@ __global__ __launch_bounds__(256) void distance_matrix_kernel(const float* __res
     const uint32_t t = threadIdx.x, r = t & 63, g = t >> 6;
     const uint64_t row0 = (uint64_t)blockIdx.x * DM_ROWS;
     const uint32_t q0 = blockIdx.y * DM_Q;
+    if (arith == NEEDLE_ARITH_AVX2 && avx2_metric(metric)) {
+        // the AVX2-build order (eight lane sums per accumulator) is not staged: every thread walks its own row and queries
+        if (row0 + r < n)
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t qi = q0 + g * 4 + j;
+                if (qi < nq) out[(uint64_t)qi * n + row0 + r] = exact_avx2(metric, queries + (uint64_t)qi * dim, base + (row0 + r) * dim, dim);
+            }
+        return;  // uniform over the workgroup
+    }
     const int kind = ref_kind(metric, arith);
     // Rust's f32 Sum folds from -0.0; the chunked sums, the service's cosine and Chebyshev's fold(0.0, max) start at +0.0
     const float zero = (kind == RK_SV_COS || kind == RK_CHEB || arith == NEEDLE_ARITH_ACCEL_CHUNK4) ? 0.0f : -0.0f;

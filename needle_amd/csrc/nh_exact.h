@@ -3,7 +3,8 @@
 // These reproduce the reference's default-build arithmetic bit for bit: one
 // rounding per multiply and per add (the translation units are compiled with
 // -ffp-contract=off), IEEE-correct sqrt and divide
-// (-fhip-fp32-correctly-rounded-divide-sqrt), subnormals kept.
+// (-fhip-fp32-correctly-rounded-divide-sqrt), subnormals kept.  The one fused
+// operation is the explicit fma of the AVX2-build order (exact_avx2).
 #pragma once
 #include "nh_common.h"
 
@@ -175,9 +176,99 @@ __device__ inline float exact_service(int metric, const float* __restrict__ q, c
     return 1.0f - (dot / den);
 }
 
+// ---- src/distance.rs:481-591: the arithmetic of a reference build with AVX2 enabled ----
+// Eight lane sums from +0.0; lane l folds elements l, l + 8, l + 16, ... with ONE rounding per element (a fused
+// multiply-add; Manhattan: a plain add of |a - b|); the lanes are folded as hsum_avx does (:489-496),
+// ((l0 + l4) + (l2 + l6)) + ((l1 + l5) + (l3 + l7)); the dim % 8 tail is then added to that result one product at a time
+// (multiply and add rounded separately).
+enum AvxOp { AVX_DOT = 0, AVX_L2 = 1, AVX_L1 = 2 };
+struct AvxAcc { float l[8]; float r; };  // lane sums; r: the folded sum, once the tail has begun
+
+__device__ inline void avx_init(AvxAcc& s) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s.l[j] = 0.0f;
+    s.r = 0.0f;
+}
+__device__ inline float avx_hsum(const float (&l)[8]) {
+    const float s0 = l[0] + l[4], s1 = l[1] + l[5], s2 = l[2] + l[6], s3 = l[3] + l[7];
+    const float t0 = s0 + s2, t1 = s1 + s3;
+    return t0 + t1;
+}
+// elements [i0, i1) of the two vectors, at x[0 ..] and y[0 ..]; i0 is a multiple of 8, i1 a multiple of 8 or dim
+template <int OP>
+__device__ inline void avx_accumulate(AvxAcc& s, const float* x, const float* y, uint32_t i0, uint32_t i1, uint32_t dim) {
+    const uint32_t vec_end = dim & ~7u;
+    uint32_t i = i0;
+    for (; i + 8 <= i1 && i + 8 <= vec_end; i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a = x[i - i0 + j], b = y[i - i0 + j];
+            if (OP == AVX_DOT) {
+                s.l[j] = __builtin_fmaf(a, b, s.l[j]);
+            } else if (OP == AVX_L2) {
+                const float d = a - b;
+                s.l[j] = __builtin_fmaf(d, d, s.l[j]);
+            } else {
+                const float d = a - b;
+                s.l[j] = s.l[j] + fabsf(d);
+            }
+        }
+    }
+    for (; i < i1; ++i) {  // the tail: i >= vec_end
+        if (i == vec_end) s.r = avx_hsum(s.l);
+        const float a = x[i - i0], b = y[i - i0];
+        if (OP == AVX_DOT) {
+            const float pr = a * b;
+            s.r = s.r + pr;
+        } else if (OP == AVX_L2) {
+            const float d = a - b;
+            const float pr = d * d;
+            s.r = s.r + pr;
+        } else {
+            s.r = s.r + fabsf(a - b);
+        }
+    }
+}
+__device__ inline float avx_finish(const AvxAcc& s, uint32_t dim) { return (dim & 7u) ? s.r : avx_hsum(s.l); }
+
+// does the AVX2 build compute this metric differently from the scalar build?  (Hamming and Chebyshev have no SIMD form)
+__device__ __host__ inline bool avx2_metric(int metric) {
+    return metric == NEEDLE_METRIC_COSINE || metric == NEEDLE_METRIC_COSINE_NORMALIZED || metric == NEEDLE_METRIC_EUCLIDEAN ||
+           metric == NEEDLE_METRIC_DOT_PRODUCT || metric == NEEDLE_METRIC_MANHATTAN;
+}
+// the metric's distance from the finished sums: a = q.b (or the squared / absolute differences), b = q.q, c = b.b
+__device__ inline float avx2_distance(int metric, float a, float qq, float bb) {
+    switch (metric) {
+    case NEEDLE_METRIC_COSINE: {  // distance.rs:153-164
+        const float na = sqrtf(qq), nb = sqrtf(bb);
+        if (na == 0.0f || nb == 0.0f) return 1.0f;
+        const float den = na * nb;
+        return 1.0f - (a / den);
+    }
+    case NEEDLE_METRIC_COSINE_NORMALIZED: return 1.0f - a;  // :193-196
+    case NEEDLE_METRIC_EUCLIDEAN: return sqrtf(a);          // :203-228
+    case NEEDLE_METRIC_DOT_PRODUCT: return -a;              // :264-266
+    default: return a;                                      // Manhattan, :323-339
+    }
+}
+__device__ inline float exact_avx2(int metric, const float* __restrict__ q, const float* __restrict__ b, uint32_t dim) {
+    if (!avx2_metric(metric)) return exact_rs(metric, q, b, dim);
+    AvxAcc s, sq, sb;
+    avx_init(s); avx_init(sq); avx_init(sb);
+    if (metric == NEEDLE_METRIC_EUCLIDEAN) avx_accumulate<AVX_L2>(s, q, b, 0, dim, dim);
+    else if (metric == NEEDLE_METRIC_MANHATTAN) avx_accumulate<AVX_L1>(s, q, b, 0, dim, dim);
+    else avx_accumulate<AVX_DOT>(s, q, b, 0, dim, dim);
+    if (metric == NEEDLE_METRIC_COSINE) {
+        avx_accumulate<AVX_DOT>(sq, q, q, 0, dim, dim);
+        avx_accumulate<AVX_DOT>(sb, b, b, 0, dim, dim);
+    }
+    return avx2_distance(metric, avx_finish(s, dim), avx_finish(sq, dim), avx_finish(sb, dim));
+}
+
 __device__ inline float exact_distance(int metric, int arith, const float* __restrict__ q,
                                        const float* __restrict__ b, uint32_t dim) {
     if (arith == NEEDLE_ARITH_SERVICE) return exact_service(metric, q, b, dim);
+    if (arith == NEEDLE_ARITH_AVX2) return exact_avx2(metric, q, b, dim);
     return arith == NEEDLE_ARITH_ACCEL_CHUNK4 ? exact_chunk4(metric, q, b, dim)
                                               : exact_rs(metric, q, b, dim);
 }

@@ -111,8 +111,102 @@ NDL_API float ndl_chebyshev(const float *a, const float *b, size_t n) {
     return m;
 }
 
+/* ------------------------------------------------------------------ */
+/* src/distance.rs:481-591: the same functions in a build with AVX2     */
+/* enabled (-C target-cpu=native / target-feature=+avx2)                */
+/* ------------------------------------------------------------------ */
+/* Eight lane sums from +0.0; lane l folds elements l, l + 8, l + 16, ... with one
+ * FUSED multiply-add each (_mm256_fmadd_ps: a single rounding); the lanes are then
+ * folded as hsum_avx does (:489-496): [l0+l4, l1+l5, l2+l6, l3+l7], then
+ * [s0+s2, s1+s3], then their sum; the len % 8 tail is added to that result one
+ * product at a time (multiply and add rounded separately).  fmaf() is the C
+ * library's correctly rounded fused multiply-add whatever the host CPU. */
+static float avx2_hsum(const float *l) {
+    float s0 = l[0] + l[4], s1 = l[1] + l[5], s2 = l[2] + l[6], s3 = l[3] + l[7];
+    float t0 = s0 + s2, t1 = s1 + s3;
+    return t0 + t1;
+}
+
+/* dot_product_avx2, src/distance.rs:505-526. */
+NDL_API float ndl_dot_avx2(const float *a, const float *b, size_t n) {
+    float l[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    size_t chunks = n / 8;
+    for (size_t c = 0; c < chunks; ++c)
+        for (int j = 0; j < 8; ++j) l[j] = fmaf(a[c * 8 + j], b[c * 8 + j], l[j]);
+    float r = avx2_hsum(l);
+    for (size_t i = chunks * 8; i < n; ++i) {
+        float p = a[i] * b[i];
+        r = r + p;
+    }
+    return r;
+}
+
+/* euclidean_squared_avx2, src/distance.rs:535-558. */
+NDL_API float ndl_euclidean_squared_avx2(const float *a, const float *b, size_t n) {
+    float l[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    size_t chunks = n / 8;
+    for (size_t c = 0; c < chunks; ++c)
+        for (int j = 0; j < 8; ++j) {
+            float d = a[c * 8 + j] - b[c * 8 + j];
+            l[j] = fmaf(d, d, l[j]);
+        }
+    float r = avx2_hsum(l);
+    for (size_t i = chunks * 8; i < n; ++i) {
+        float d = a[i] - b[i];
+        float p = d * d;
+        r = r + p;
+    }
+    return r;
+}
+
+/* manhattan_avx2, src/distance.rs:567-591 (the sign bit cleared, plain adds). */
+NDL_API float ndl_manhattan_avx2(const float *a, const float *b, size_t n) {
+    float l[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    size_t chunks = n / 8;
+    for (size_t c = 0; c < chunks; ++c)
+        for (int j = 0; j < 8; ++j) l[j] = l[j] + fabsf(a[c * 8 + j] - b[c * 8 + j]);
+    float r = avx2_hsum(l);
+    for (size_t i = chunks * 8; i < n; ++i) r = r + fabsf(a[i] - b[i]);
+    return r;
+}
+
+/* DistanceFunction::compute in that build: cosine (:153-164), cosine_normalized
+ * (:193-196), euclidean (:203-228), dot product (:264-304) and manhattan
+ * (:323-339) go through the AVX2 functions; hamming and chebyshev have no SIMD
+ * form. */
+#define NDL_AVX2_ORDER 0x100 /* or-ed into a metric: that build's arithmetic */
+static float ndl_compute_avx2(int metric, const float *a, const float *b, size_t n) {
+    switch (metric) {
+    case NDL_COSINE: {
+        float dot = ndl_dot_avx2(a, b, n);
+        float na = sqrtf(ndl_dot_avx2(a, a, n));
+        float nb = sqrtf(ndl_dot_avx2(b, b, n));
+        if (na == 0.0f || nb == 0.0f) return 1.0f;
+        return 1.0f - (dot / (na * nb));
+    }
+    case NDL_COSINE_NORMALIZED: return 1.0f - ndl_dot_avx2(a, b, n);
+    case NDL_EUCLIDEAN: return sqrtf(ndl_euclidean_squared_avx2(a, b, n));
+    case NDL_DOT_PRODUCT: return -ndl_dot_avx2(a, b, n);
+    case NDL_MANHATTAN: return ndl_manhattan_avx2(a, b, n);
+    case NDL_HAMMING: return ndl_hamming(a, b, n);
+    case NDL_CHEBYSHEV: return ndl_chebyshev(a, b, n);
+    default: return NAN;
+    }
+}
+
+/* normalize (:426-455) in that build: the norm from dot_product_avx2, the scaling
+ * a multiply per element either way. */
+NDL_API void ndl_normalize_avx2(float *v, size_t n) {
+    float norm = sqrtf(ndl_dot_avx2(v, v, n));
+    if (norm > 0.0f) {
+        float inv = 1.0f / norm;
+        for (size_t i = 0; i < n; ++i) v[i] = v[i] * inv;
+    }
+}
+
 /* DistanceFunction::compute, src/distance.rs:93-103. */
 NDL_API float ndl_compute(int metric, const float *a, const float *b, size_t n) {
+    if (metric & NDL_AVX2_ORDER) return ndl_compute_avx2(metric & ~NDL_AVX2_ORDER, a, b, n);
     switch (metric) {
     case NDL_COSINE: return ndl_cosine(a, b, n);
     case NDL_COSINE_NORMALIZED: return ndl_cosine_normalized(a, b, n);

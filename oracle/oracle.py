@@ -49,7 +49,7 @@ def _declare(L: C.CDLL) -> None:
     _declare_hnsw(L)
     for name in ("ndl_dot", "ndl_euclidean_squared", "ndl_euclidean", "ndl_cosine", "ndl_cosine_normalized",
                  "ndl_dot_distance", "ndl_manhattan", "ndl_hamming", "ndl_chebyshev", "ndl_dot_chunk4",
-                 "ndl_euclidean_chunk4"):
+                 "ndl_euclidean_chunk4", "ndl_dot_avx2", "ndl_euclidean_squared_avx2", "ndl_manhattan_avx2"):
         f = getattr(L, name)
         f.restype = C.c_float
         f.argtypes = [_f32p, _f32p, sz]
@@ -59,6 +59,8 @@ def _declare(L: C.CDLL) -> None:
     L.ndl_cosine_chunk4_precomputed.argtypes = [_f32p, _f32p, sz, C.c_float]
     L.ndl_normalize.restype = None
     L.ndl_normalize.argtypes = [_f32p, sz]
+    L.ndl_normalize_avx2.restype = None
+    L.ndl_normalize_avx2.argtypes = [_f32p, sz]
     L.ndl_metric_from_str.restype = C.c_int
     L.ndl_metric_from_str.argtypes = [C.c_char_p]
     L.ndl_validate_vector.restype = C.c_int
@@ -219,6 +221,12 @@ hamming = _pair("ndl_hamming")
 chebyshev = _pair("ndl_chebyshev")
 dot_chunk4 = _pair("ndl_dot_chunk4")
 euclidean_chunk4 = _pair("ndl_euclidean_chunk4")
+# the arithmetic of a reference build with AVX2 enabled (src/distance.rs:481-591); AVX2_ORDER or-ed into a metric selects
+# it in compute() and flat_batch_search()
+AVX2_ORDER = 0x100
+dot_avx2 = _pair("ndl_dot_avx2")
+euclidean_squared_avx2 = _pair("ndl_euclidean_squared_avx2")
+manhattan_avx2 = _pair("ndl_manhattan_avx2")
 
 
 def cosine_chunk4_precomputed(a, b, a_norm: float) -> float:
@@ -226,9 +234,9 @@ def cosine_chunk4_precomputed(a, b, a_norm: float) -> float:
     return float(lib().ndl_cosine_chunk4_precomputed(_p(a, _f32p), _p(b, _f32p), a.size, C.c_float(a_norm)))
 
 
-def normalized(v) -> np.ndarray:
+def normalized(v, avx2: bool = False) -> np.ndarray:
     out = _f32(v).copy()
-    lib().ndl_normalize(_p(out, _f32p), out.size)
+    (lib().ndl_normalize_avx2 if avx2 else lib().ndl_normalize)(_p(out, _f32p), out.size)
     return out
 
 
