@@ -82,6 +82,9 @@ def parse(argv=None):
     ap.add_argument("--ivf-leg-seconds", type=float, default=420.0, help="N > 1: time limit of the row-sharded IVF leg")
     ap.add_argument("--parity-queries", type=int, default=16, help="N > 1: queries rank 0 checks against the oracle (0 = skip)")
     ap.add_argument("--paths", default=DEFAULT_PATHS, help="N = 1: other configurations folded into the line ('none' = skip)")
+    ap.add_argument("--hnsw-rows", type=int, default=100_000, help="rows of the CPU HNSW baseline in `paths` (sequential build)")
+    ap.add_argument("--hnsw-seconds", type=float, default=150.0,
+                    help="time budget of that build: it stops there and the baseline covers the rows that are in")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per first-pass launch from a separate rocprofv3 --pmc run")
     ap.add_argument("--backend", default="hip",
@@ -263,7 +266,8 @@ class HipBackend:
     def paths(self, want, oracle):
         import tools.bench_paths as bp
 
-        return bp.run_paths(self.ctx, self.device, want, steps=2, oracle=oracle)
+        return bp.run_paths(self.ctx, self.device, want, steps=2, oracle=oracle, hnsw_rows=getattr(self, "hnsw_rows", 100_000),
+                            hnsw_budget_s=getattr(self, "hnsw_budget_s", 150.0))
 
     def close(self):
         if self.comm is not None:
@@ -448,6 +452,7 @@ def run(args, be):
     if not sharded_ivf:
         del base
     if rank == 0 and world == 1 and want_paths:
+        be.hnsw_rows, be.hnsw_budget_s = args.hnsw_rows, args.hnsw_seconds
         paths = be.paths(want_paths, orc)
 
     line = None

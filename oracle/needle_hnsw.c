@@ -88,6 +88,8 @@ typedef struct {
     int64_t entry_point; uint32_t entry_level;
     size_t count;
     uint64_t rng;
+    int fast_build; /* the build scores several rows at a time (same bits, see dist_many) */
+    float *bb; uint8_t *bb_known; /* fast build, cosine: b.b of a row, summed once (the sum every pair would repeat) */
 } ndl_hnsw;
 
 static inline uint64_t hn_splitmix64(uint64_t *s) {
@@ -125,13 +127,80 @@ NDL_API ndl_hnsw *ndl_hnsw_new(const float *vectors, size_t n_cap, size_t dim, i
     h->deleted = calloc(n_cap ? n_cap : 1, 1);
     h->entry_point = -1;
     h->rng = seed;
+    h->fast_build = 1;
+    h->bb = malloc((n_cap ? n_cap : 1) * sizeof(float));
+    h->bb_known = calloc(n_cap ? n_cap : 1, 1);
     return h;
 }
 
 NDL_API void ndl_hnsw_free(ndl_hnsw *h) {
     if (!h) return;
     free(h->adj0); free(h->cnt0); free(h->adj_up); free(h->cnt_up); free(h->up_off);
-    free(h->level); free(h->present); free(h->deleted); free(h);
+    free(h->level); free(h->present); free(h->deleted); free(h->bb); free(h->bb_known); free(h);
+}
+
+/* The BUILD's distances, several rows at a time.  Every row's sums are the sequences ndl_compute runs -- the same
+ * operations in the same order per row, so the same bits -- but the chains of eight rows are interleaved, which fills
+ * the adder's latency instead of waiting it out once per element.  Of the cosine's three sums, q.q is one and the same
+ * for every row (the caller passes it in) and b.b is the same whenever row b is scored (kept after its first use).  The timed searches do not come through here:
+ * they pay what the reference pays (one DistanceFunction::compute per neighbour). */
+float ndl_dot(const float *a, const float *b, size_t n); /* needle_oracle.c */
+enum { HN_COSINE = 0, HN_COSINE_NORMALIZED = 1, HN_EUCLIDEAN = 2, HN_DOT_PRODUCT = 3 };
+
+static void dist_many(const ndl_hnsw *h, const float *q, float qq, const uint32_t *ids, size_t n, float *out) {
+    const size_t dim = h->dim;
+    if (h->metric == HN_COSINE) {
+        const float na = sqrtf(qq);
+        for (size_t j = 0; j < n; j++)
+            if (!h->bb_known[ids[j]]) {  /* (only the single-threaded build comes here) */
+                const float *r = h->vectors + (size_t)ids[j] * dim;
+                h->bb[ids[j]] = ndl_dot(r, r, dim);
+                h->bb_known[ids[j]] = 1;
+            }
+        for (size_t g = 0; g < n; g += 8) {
+            const float *r[8];
+            float s[8];
+            for (int j = 0; j < 8; j++) {
+                r[j] = h->vectors + (size_t)ids[g + (size_t)j < n ? g + (size_t)j : n - 1] * dim;
+                s[j] = -0.0f;
+            }
+            for (size_t i = 0; i < dim; i++) {
+                const float x = q[i];
+                for (int j = 0; j < 8; j++) { const float p = x * r[j][i]; s[j] = s[j] + p; }
+            }
+            for (int j = 0; j < 8 && g + (size_t)j < n; j++) {
+                const float nb = sqrtf(h->bb[ids[g + (size_t)j]]);
+                out[g + (size_t)j] = (na == 0.0f || nb == 0.0f) ? 1.0f : 1.0f - (s[j] / (na * nb));
+            }
+        }
+        return;
+    }
+    if (h->metric == HN_COSINE_NORMALIZED || h->metric == HN_EUCLIDEAN || h->metric == HN_DOT_PRODUCT) {
+        const int l2 = h->metric == HN_EUCLIDEAN;
+        for (size_t g = 0; g < n; g += 8) {
+            const float *r[8];
+            float s[8];
+            for (int j = 0; j < 8; j++) {
+                r[j] = h->vectors + (size_t)ids[g + (size_t)j < n ? g + (size_t)j : n - 1] * dim;
+                s[j] = -0.0f;
+            }
+            if (l2) {
+                for (size_t i = 0; i < dim; i++) {
+                    const float x = q[i];
+                    for (int j = 0; j < 8; j++) { const float d = x - r[j][i]; const float p = d * d; s[j] = s[j] + p; }
+                }
+            } else {
+                for (size_t i = 0; i < dim; i++) {
+                    const float x = q[i];
+                    for (int j = 0; j < 8; j++) { const float p = x * r[j][i]; s[j] = s[j] + p; }
+                }
+            }
+            for (int j = 0; j < 8 && g + (size_t)j < n; j++)
+                out[g + (size_t)j] = l2 ? sqrtf(s[j]) : (h->metric == HN_DOT_PRODUCT ? -s[j] : 1.0f - s[j]);
+        }
+        return;
+    }
+    for (size_t j = 0; j < n; j++) out[j] = ndl_compute(h->metric, q, h->vectors + (size_t)ids[j] * dim, dim);
 }
 
 /* search_layer_core, :957-1017.  `visited` is a zeroed n_cap-byte array, as the reference allocates one per call
@@ -139,8 +208,13 @@ NDL_API void ndl_hnsw_free(ndl_hnsw *h) {
  * costs less than the reference's fresh allocation -- the timing baseline passes NULL to get the reference's cost.
  * Results: closest first; returns the count, at most ef (at least the entry when it is not deleted). */
 static size_t search_layer(const ndl_hnsw *h, const float *query, uint32_t entry, size_t ef, uint32_t layer,
-                           uint8_t *visited_in, hn_item **out, size_t *out_cap, size_t *visited_count) {
+                           uint8_t *visited_in, hn_item **out, size_t *out_cap, size_t *visited_count, int fast) {
     uint8_t *visited = visited_in ? visited_in : calloc(h->n_cap, 1);
+    /* fast (the build): the unvisited neighbours of a candidate are scored together; they are marked, and afterwards
+     * offered to the heaps, in list order, against the `worst` read before -- what the loop below does one by one */
+    uint32_t *fresh = fast ? malloc(((size_t)h->m_max_0 + 1) * sizeof(uint32_t)) : NULL;
+    float *fresh_d = fast ? malloc(((size_t)h->m_max_0 + 1) * sizeof(float)) : NULL;
+    const float qq = (fast && h->metric == HN_COSINE) ? ndl_dot(query, query, h->dim) : 0.0f;
     uint32_t *log = NULL; size_t nlog = 0, caplog = 0;
     hn_heap cand = {0}, res = {0};
     res.max_heap = 1;
@@ -157,11 +231,26 @@ static size_t search_layer(const ndl_hnsw *h, const float *query, uint32_t entry
         if (c.d > worst && res.n >= ef) break;
         uint16_t *cnt; const uint32_t *nb = conns(h, c.id, layer, &cnt);
         uint16_t nnb = *cnt;
-        for (uint16_t j = 0; j < nnb; j++) {
-            uint32_t x = nb[j];
-            if (visited[x]) continue;
-            MARK(x); nvis++;
-            float d = ndl_compute(h->metric, query, h->vectors + (size_t)x * h->dim, h->dim);
+        size_t nfresh = 0;
+        if (fast) {
+            for (uint16_t j = 0; j < nnb; j++) {
+                uint32_t x = nb[j];
+                if (visited[x]) continue;
+                MARK(x); nvis++;
+                fresh[nfresh++] = x;
+            }
+            dist_many(h, query, qq, fresh, nfresh, fresh_d);
+        }
+        for (size_t j = 0; j < (fast ? nfresh : (size_t)nnb); j++) {
+            uint32_t x = fast ? fresh[j] : nb[j];
+            float d;
+            if (fast) {
+                d = fresh_d[j];
+            } else {
+                if (visited[x]) continue;
+                MARK(x); nvis++;
+                d = ndl_compute(h->metric, query, h->vectors + (size_t)x * h->dim, h->dim);
+            }
             /* worst_dist is read once per popped candidate (:982), not per neighbour */
             if (d < worst || res.n < ef) {
                 heap_push(&cand, (hn_item){d, x});
@@ -180,7 +269,7 @@ static size_t search_layer(const ndl_hnsw *h, const float *query, uint32_t entry
     for (size_t i = n; i-- > 0;) (*out)[i] = heap_pop(&res);
     if (visited_in) { for (size_t i = 0; i < nlog; i++) visited[log[i]] = 0; free(log); }
     else free(visited);
-    free(cand.v); free(res.v);
+    free(cand.v); free(res.v); free(fresh); free(fresh_d);
     if (visited_count) *visited_count += nvis;
     return n;
 }
@@ -252,15 +341,16 @@ NDL_API int ndl_hnsw_insert(ndl_hnsw *h, uint32_t id) {
     hn_item *cand = NULL; size_t cand_cap = 0;
     uint8_t *visited = calloc(h->n_cap, 1);
     for (uint32_t l = h->entry_level; l > level; l--) {
-        size_t n = search_layer(h, vec, current, 1, l, visited, &cand, &cand_cap, NULL);
+        size_t n = search_layer(h, vec, current, 1, l, visited, &cand, &cand_cap, NULL, h->fast_build);
         if (n) current = cand[0].id;
     }
     uint32_t start = level < h->entry_level ? level : h->entry_level;
     size_t tmp_cap = 2 * ((size_t)h->ef_construction + h->m_max_0 + 2);
     hn_item *tmp = malloc(tmp_cap * sizeof(hn_item)), *scored = malloc((h->m_max_0 + 2) * sizeof(hn_item));
     hn_item *nbrs = malloc(((size_t)h->ef_construction + 1) * sizeof(hn_item));
+    float *prune_d = malloc(((size_t)h->m_max_0 + 2) * sizeof(float));
     for (uint32_t l = start + 1; l-- > 0;) {
-        size_t nc = search_layer(h, vec, current, h->ef_construction, l, visited, &cand, &cand_cap, NULL);
+        size_t nc = search_layer(h, vec, current, h->ef_construction, l, visited, &cand, &cand_cap, NULL, h->fast_build);
         uint32_t first = nc ? cand[0].id : current;
         memcpy(nbrs, cand, nc * sizeof(hn_item));
         size_t nn = select_neighbors(nbrs, nc, max_conn(h, l), tmp);
@@ -276,9 +366,14 @@ NDL_API int ndl_hnsw_insert(ndl_hnsw *h, uint32_t id) {
             if (*ncnt > mc) {
                 const float *nv = h->vectors + (size_t)nb * h->dim;
                 size_t ns = *ncnt;
-                for (size_t j = 0; j < ns; j++) {
-                    scored[j].id = nl[j];
-                    scored[j].d = ndl_compute(h->metric, nv, h->vectors + (size_t)nl[j] * h->dim, h->dim);
+                if (h->fast_build) {
+                    dist_many(h, nv, h->metric == HN_COSINE ? ndl_dot(nv, nv, h->dim) : 0.0f, nl, ns, prune_d);
+                    for (size_t j = 0; j < ns; j++) { scored[j].id = nl[j]; scored[j].d = prune_d[j]; }
+                } else {
+                    for (size_t j = 0; j < ns; j++) {
+                        scored[j].id = nl[j];
+                        scored[j].d = ndl_compute(h->metric, nv, h->vectors + (size_t)nl[j] * h->dim, h->dim);
+                    }
                 }
                 size_t kept = select_neighbors(scored, ns, mc, tmp);
                 for (size_t j = 0; j < kept; j++) nl[j] = scored[j].id;
@@ -287,7 +382,7 @@ NDL_API int ndl_hnsw_insert(ndl_hnsw *h, uint32_t id) {
         }
         if (nc) current = first;
     }
-    free(tmp); free(scored); free(nbrs); free(cand); free(visited);
+    free(tmp); free(scored); free(nbrs); free(prune_d); free(cand); free(visited);
     if (level > h->entry_level) { h->entry_point = id; h->entry_level = level; }
     h->count++;
     return 0;
@@ -304,6 +399,7 @@ NDL_API int ndl_hnsw_delete(ndl_hnsw *h, uint32_t id) { /* :1039-1047: mark only
 }
 
 NDL_API size_t ndl_hnsw_len(const ndl_hnsw *h) { return h->count; }
+NDL_API void ndl_hnsw_set_fast_build(ndl_hnsw *h, int on) { h->fast_build = on; } /* 0: the build scores row by row too */
 NDL_API void ndl_hnsw_set_ef_search(ndl_hnsw *h, uint32_t ef) { h->ef_search = ef; } /* :566-568 */
 NDL_API uint32_t ndl_hnsw_entry_level(const ndl_hnsw *h) { return h->entry_level; }
 NDL_API size_t ndl_hnsw_degree(const ndl_hnsw *h, uint32_t id, uint32_t layer) {
@@ -317,10 +413,10 @@ NDL_API size_t ndl_hnsw_search(const ndl_hnsw *h, const float *query, size_t k, 
     uint32_t current = (uint32_t)h->entry_point;
     hn_item *cand = NULL; size_t cap = 0, vis = 0;
     for (uint32_t l = h->entry_level; l >= 1; l--) {
-        size_t n = search_layer(h, query, current, 1, l, NULL, &cand, &cap, &vis);
+        size_t n = search_layer(h, query, current, 1, l, NULL, &cand, &cap, &vis, 0);
         if (n) current = cand[0].id;
     }
-    size_t n = search_layer(h, query, current, ef, 0, NULL, &cand, &cap, &vis);
+    size_t n = search_layer(h, query, current, ef, 0, NULL, &cand, &cap, &vis, 0);
     if (n > k) n = k;
     for (size_t i = 0; i < n; i++) { out_ids[i] = cand[i].id; out_dists[i] = cand[i].d; }
     free(cand);

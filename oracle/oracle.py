@@ -666,6 +666,8 @@ def _declare_hnsw(L: C.CDLL) -> None:
     L.ndl_hnsw_set_ef_search.argtypes = [vp, C.c_uint32]
     L.ndl_hnsw_len.restype = sz
     L.ndl_hnsw_len.argtypes = [vp]
+    L.ndl_hnsw_set_fast_build.restype = None
+    L.ndl_hnsw_set_fast_build.argtypes = [vp, C.c_int]
     L.ndl_hnsw_entry_level.restype = C.c_uint32
     L.ndl_hnsw_entry_level.argtypes = [vp]
     L.ndl_hnsw_degree.restype = sz
@@ -682,13 +684,16 @@ class Hnsw:
     reference's are unseeded), so a graph is reproducible here and unpinned against the reference."""
 
     def __init__(self, vectors, metric: int, m: int = 16, m_max_0: int | None = None, ef_construction: int = 200,
-                 ef_search: int = 50, seed: int = 42):
+                 ef_search: int = 50, seed: int = 42, fast_build: bool = True):
         self.vectors = _f32(vectors).reshape(len(vectors), -1) if len(vectors) else np.zeros((0, 1), np.float32)
         self.ef_search = ef_search
         self._h = lib().ndl_hnsw_new(_p(self.vectors, _f32p), self.vectors.shape[0], self.vectors.shape[1], metric, m,
                                      2 * m if m_max_0 is None else m_max_0, ef_construction, ef_search, seed)
         if not self._h:
             raise ValueError("invalid HNSW configuration")  # HnswConfig::validate, :326-357
+        # the build scores the unvisited neighbours of a candidate together (interleaved sums: the same bits, several
+        # times the speed); False: row by row, as the searches always do
+        lib().ndl_hnsw_set_fast_build(self._h, int(fast_build))
 
     def insert(self, row: int) -> None:
         if lib().ndl_hnsw_insert(self._h, row) != 0:

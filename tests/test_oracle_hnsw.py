@@ -98,3 +98,25 @@ def test_batch_search_equals_single_searches_and_is_thread_count_independent():
     for i in (0, 17, 39):
         ids, dists, _ = h.search(q[i], 10)
         assert np.array_equal(ids, ids1[i, : c1[i]]) and np.array_equal(dists, d1[i, : c1[i]])
+
+
+@pytest.mark.parametrize("metric", ["COSINE", "COSINE_NORMALIZED", "EUCLIDEAN", "DOT_PRODUCT", "MANHATTAN"])
+def test_the_builds_batched_distances_leave_the_graph_unchanged(metric):
+    """The build scores the unvisited neighbours of a candidate together (interleaved sums, norms kept per row): every
+    adjacency list and every search result equals those of the row-by-row build, bit for bit."""
+    rng = np.random.default_rng(11)
+    v = rng.standard_normal((1500, 37)).astype(np.float32)
+    v[40] = 0.0            # a zero norm
+    v[900] = v[41]         # equal distances
+    q = rng.standard_normal((30, 37)).astype(np.float32)
+    m = getattr(O, metric)
+    graphs = []
+    for fast in (True, False):
+        h = O.Hnsw(v, m, m=8, ef_construction=60, fast_build=fast)
+        h.insert_range(0, 1500)
+        ids, d, c = h.batch_search(q, 10, threads=2)
+        graphs.append((ids.copy(), d.copy().view(np.uint32), c.copy(), [h.degree(i, 0) for i in range(1500)],
+                       [h.degree(i, 1) for i in range(1500)], h.entry_level))
+        h.close()
+    for a, b in zip(graphs[0], graphs[1]):
+        assert np.array_equal(a, b)
