@@ -88,6 +88,8 @@ pub struct needle_hip_metrics {
     pub binary_code_scans: u64,
     pub list_scans: u64,
     pub list_scan_ms_total: f64,
+    pub compacted_searches: u64,
+    pub compacted_rows: u64,
 }
 
 // ---- generated from include/needle_hip.h by tools/gen_rust_sys.py: begin ----

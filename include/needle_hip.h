@@ -136,6 +136,8 @@ typedef struct needle_hip_metrics {
     uint64_t binary_code_scans;   /* full passes over a binary code matrix (2 or 3 per batch: see needle_hip_binary_build) */
     uint64_t list_scans;          /* IVF batches whose inverted-list scan was timed (profiling on) */
     double list_scan_ms_total;    /* device time of those list scans: threshold sample, list-major scan launches, refreshes */
+    uint64_t compacted_searches;  /* filtered flat searches served from a gathered copy of the rows the masks admit */
+    uint64_t compacted_rows;      /* rows of those copies, summed */
 } needle_hip_metrics;
 
 /* ---- context --------------------------------------------------------- */

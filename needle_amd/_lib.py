@@ -53,7 +53,8 @@ class Metrics(C.Structure):
     _fields_ = [("searches", C.c_uint64), ("queries", C.c_uint64), ("fallback_queries", C.c_uint64),
                 ("scan_launches", C.c_uint64), ("scan_ms_total", C.c_double), ("last_scan_ms", C.c_double),
                 ("last_search_ms", C.c_double), ("refined_queries", C.c_uint64), ("binary_code_scans", C.c_uint64),
-                ("list_scans", C.c_uint64), ("list_scan_ms_total", C.c_double)]
+                ("list_scans", C.c_uint64), ("list_scan_ms_total", C.c_double), ("compacted_searches", C.c_uint64),
+                ("compacted_rows", C.c_uint64)]
 
 
 class NeedleHipError(RuntimeError):

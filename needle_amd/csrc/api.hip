@@ -182,7 +182,10 @@ extern "C" needle_hip_status needle_hip_set_tuning(needle_hip_ctx* c, const char
         const uint32_t i = (uint32_t)(k[5] - '0');
         if (u == 0) t.n_stage_pct = std::min(t.n_stage_pct, i);  // stageN = 0 ends the schedule before launch N
         else { t.stage_pct[i] = u; t.n_stage_pct = std::max(t.n_stage_pct, i + 1); }
-    } else if (k == "no_dense") t.no_dense = u;
+    } else if (k == "no_compact") t.no_compact = u;
+    else if (k == "compact_pct") t.compact_pct = u;
+    else if (k == "compact_min_rows") t.compact_min_rows = u;
+    else if (k == "no_dense") t.no_dense = u;
     else if (k == "no_set_only") t.no_set_only = u;
     else if (k == "merge_keys") t.merge_keys = u;
     else if (k == "merge_lists") t.merge_lists = u;
@@ -296,6 +299,8 @@ void nh::free_search_slots(needle_hip_index* ix) {
         destroy_side_stream(&s->ctx);
         release_workspace(&s->ix);
         release_workspace(&s->cent);
+        release_workspace(&s->compact);
+        for (DevBuf* b : {&s->z_raw, &s->z_op16, &s->z_op32, &s->z_cinit, &s->z_pos, &s->z_cnt}) b->release();
         for (auto& b : s->ctx.scratch) b.release();
         for (int i = 0; i < 4; ++i) if (s->ctx.ev[i]) (void)hipEventDestroy(s->ctx.ev[i]);
         (void)hipStreamDestroy(s->ctx.stream);
@@ -347,6 +352,7 @@ nh::SlotLease::SlotLease(needle_hip_index* parent, const needle_search_params* p
         fprintf(stderr, "[needle_hip] index %p: search takes slot %p (%s), stream %p\n", (void*)parent, (void*)slot_,
                 first ? "new" : "reused", (void*)slot_->ctx.stream);
     sync_view(&slot_->ix, parent, &slot_->ctx, first);
+    slot_->ix.slot = slot_;
     if (parent->centroids) {
         sync_view(&slot_->cent, parent->centroids, &slot_->ctx, first);
         slot_->ix.centroids = &slot_->cent;
@@ -368,6 +374,7 @@ nh::SlotLease::~SlotLease() {
         pc->m.searches += d.searches; pc->m.queries += d.queries; pc->m.fallback_queries += d.fallback_queries;
         pc->m.scan_launches += d.scan_launches; pc->m.scan_ms_total += d.scan_ms_total;
         pc->m.refined_queries += d.refined_queries; pc->m.binary_code_scans += d.binary_code_scans;
+        pc->m.compacted_searches += d.compacted_searches; pc->m.compacted_rows += d.compacted_rows;
         pc->m.list_scans += d.list_scans; pc->m.list_scan_ms_total += d.list_scan_ms_total;
         if (d.scan_launches) pc->m.last_scan_ms = d.last_scan_ms;
         if (d.searches && slot_->ctx.profiling) pc->m.last_search_ms = d.last_search_ms;
@@ -1283,6 +1290,75 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     return NEEDLE_HIP_OK;
 }
 
+// A filtered search of a flat index whose masks (deleted rows and the caller's filter together) admit at most half of the
+// rows does not scan the base: the admitted rows are counted (one small kernel and a 4-byte read-back), their numbers
+// listed in ascending order, and their raw rows, operands and accumulator seeds gathered into the slot's `compact`
+// index -- a flat index without masks, whose row r is row z_pos[r] of the base.  Position order is row order, so ties
+// still go to the lower row number; the maxima the bounds use (largest norm, largest rounding error) are the base's and
+// cover its subset.  *out stays null when the search should run over the base itself.
+static needle_hip_status compact_admitted_rows(needle_hip_index* ix, const uint32_t* d_filter, int precision, needle_hip_index** out,
+                                               uint32_t* out_live) {
+    *out = nullptr;
+    needle_hip_ctx* c = ix->ctx;
+    SearchSlot* s = ix->slot;
+    const Tuning& tune = c->tune;
+    const uint32_t n = (uint32_t)ix->n;
+    const uint32_t min_rows = tune.compact_min_rows ? tune.compact_min_rows : 65536u;
+    if (!s || !d_filter || ix->kind != KIND_FLAT || tune.no_compact || ix->n < min_rows || ix->n > 0xfffffff0ull ||
+        ix->cos_norm_unsafe || !metric_has_first_pass(ix->metric) || precision == NEEDLE_PRECISION_EXACT_SCAN)
+        return NEEDLE_HIP_OK;
+    const bool want_bf16 = precision == NEEDLE_PRECISION_BF16 && flat_scan_bf16_dpad(ix->dim) != 0;
+    if (want_bf16 && !ix->d_op_bf16) return NEEDLE_HIP_OK;  // (the search will not use the bf16 route either)
+    const uint32_t blocks = mask_blocks(n);
+    HIP_TRY(s->z_cnt.ensure(((size_t)blocks + 1) * sizeof(uint32_t)));
+    uint32_t* d_cnt = s->z_cnt.as<uint32_t>();  // [blocks] admitted rows per block of 8192, then their total
+    HIP_TRY(launch_mask_count(ix->d_valid, d_filter, n, d_cnt, d_cnt + blocks, c->stream));
+    uint32_t live = 0;
+    HIP_TRY(hipMemcpyAsync(&live, d_cnt + blocks, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint32_t pct = tune.compact_pct ? std::min<uint32_t>(tune.compact_pct, 100u) : 50u;
+    if (live == 0 || live > n || (uint64_t)live * 100u > (uint64_t)n * pct) return NEEDLE_HIP_OK;
+    const uint32_t n_pad = round_up(live, TILE_ROWS);
+    HIP_TRY(s->z_pos.ensure((size_t)n_pad * sizeof(uint32_t)));
+    uint32_t* d_pos = s->z_pos.as<uint32_t>();
+    HIP_TRY(launch_mask_positions(ix->d_valid, d_filter, n, d_cnt, live, d_pos, c->stream));
+    const size_t raw_bytes = (size_t)ix->dim * sizeof(float);
+    HIP_TRY(s->z_raw.ensure((size_t)n_pad * raw_bytes));
+    HIP_TRY(launch_gather_row_bytes(ix->d_raw, d_pos, live, n_pad, n, raw_bytes, s->z_raw.p, c->stream));
+    needle_hip_index& x = s->compact;
+    x.ctx = c; x.is_view = true; x.slot = nullptr; x.kind = KIND_FLAT;
+    x.n = live; x.n_pad = n_pad; x.cap_pad = n_pad; x.dim = ix->dim; x.metric = ix->metric; x.arith = ix->arith;
+    x.d_raw = s->z_raw.as<float>();
+    x.dpad_f32 = ix->dpad_f32; x.dpad_bf16 = ix->dpad_bf16; x.op_f32_alias = ix->op_f32_alias;
+    if (ix->op_f32_alias) {
+        x.d_op_f32 = x.d_raw;
+    } else {
+        const size_t b = (size_t)ix->dpad_f32 * sizeof(float);
+        HIP_TRY(s->z_op32.ensure((size_t)n_pad * b));
+        HIP_TRY(launch_gather_row_bytes(ix->d_op_f32, d_pos, live, n_pad, n, b, s->z_op32.p, c->stream));
+        x.d_op_f32 = s->z_op32.as<float>();
+    }
+    x.d_op_bf16 = nullptr;
+    if (want_bf16) {
+        const size_t b = (size_t)ix->dpad_bf16 * sizeof(uint16_t);
+        HIP_TRY(s->z_op16.ensure((size_t)n_pad * b));
+        HIP_TRY(launch_gather_row_bytes(ix->d_op_bf16, d_pos, live, n_pad, n, b, s->z_op16.p, c->stream));
+        x.d_op_bf16 = s->z_op16.as<uint16_t>();
+    }
+    x.d_cinit = nullptr;
+    if (ix->d_cinit) {
+        HIP_TRY(s->z_cinit.ensure((size_t)n_pad * sizeof(float)));
+        HIP_TRY(launch_gather_row_bytes(ix->d_cinit, d_pos, live, n_pad, n, sizeof(float), s->z_cinit.p, c->stream));
+        x.d_cinit = s->z_cinit.as<float>();
+    }
+    x.d_norms = nullptr; x.d_valid = nullptr; x.d_unsafe = nullptr; x.n_unsafe = 0; x.cos_norm_unsafe = false;
+    x.max_norm = ix->max_norm; x.min_norm = ix->min_norm; x.bf16_err = ix->bf16_err;
+    x.bf16_extra_slack = std::max(x.bf16_extra_slack, ix->bf16_extra_slack);
+    *out = &x;
+    *out_live = live;
+    return NEEDLE_HIP_OK;
+}
+
 static needle_hip_status search_device_locked(needle_hip_index* ix, const float* d_queries, uint32_t q,
                                               const needle_search_params* params, const uint32_t* d_filter,
                                               uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts) {
@@ -1302,6 +1378,14 @@ static needle_hip_status search_device_locked(needle_hip_index* ix, const float*
         HIP_TRY(launch_fill_empty(d_out_ids, d_out_dists, d_out_counts, q, k, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     } else {
+        needle_hip_index* base_ix = ix;
+        needle_hip_index* compact = nullptr;
+        uint32_t compact_live = 0;
+        ST_TRY(compact_admitted_rows(ix, d_filter, precision, &compact, &compact_live));
+        if (compact) {  // the admitted rows as an index of their own: no masks left
+            ix = compact;
+            d_filter = nullptr;
+        }
         const uint32_t QB = 16384;
         for (uint32_t q0 = 0; q0 < q; q0 += QB) {
             const uint32_t qb = std::min(QB, q - q0);
@@ -1326,6 +1410,14 @@ static needle_hip_status search_device_locked(needle_hip_index* ix, const float*
                                                 d_out_ids + (size_t)q0 * k, d_out_dists + (size_t)q0 * k,
                                                 d_out_counts + q0));
         }
+        if (compact) {
+            HIP_TRY(launch_map_ids(d_out_ids, (uint64_t)q * k, base_ix->slot->z_pos.as<uint32_t>(), compact_live, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            std::lock_guard g(c->mu);
+            c->m.compacted_searches += 1;
+            c->m.compacted_rows += compact_live;
+        }
+        ix = base_ix;
     }
     if (c->profiling) {
         HIP_TRY(hipEventRecord(c->ev[3], c->stream));

@@ -75,6 +75,9 @@ struct Tuning {
     int32_t pre_tiles = -1;      // tiles per slice the threshold pre-pass samples
     uint32_t kseed = 0;          // rank of the seeded threshold among the sampled group maxima
     float band = 0.0f;           // width of the threshold band in score uncertainties
+    uint32_t no_compact = 0;     // 1: a filtered flat search never scans a gathered copy of the admitted rows
+    uint32_t compact_pct = 0;    // largest admitted share (percent of the rows) that still takes the gathered copy (0: 50)
+    uint32_t compact_min_rows = 0;  // smallest base that does (0: 65536 rows)
     uint32_t stage_pct[4] = {0, 0, 0, 0};  // share of a slice per staged launch (the last launch takes the rest)
     uint32_t n_stage_pct = 0;
     uint32_t no_dense = 0;       // small bases take the candidate lists instead of the dense score matrix
@@ -177,6 +180,7 @@ struct needle_hip_index {
     std::condition_variable pool_cv;
     std::vector<nh::SearchSlot*> slots;
     bool is_view = false;
+    nh::SearchSlot* slot = nullptr;  // a view: the search slot it belongs to
 };
 
 namespace nh {
@@ -188,6 +192,11 @@ struct SearchSlot {
     needle_hip_ctx ctx;       // device and CU count of the parent context; stream, events and metrics of its own
     needle_hip_index ix;      // view of the parent index
     needle_hip_index cent;    // view of the parent's centroid index (IVF)
+    // A filtered search of a flat index whose masks admit a small part of the rows scans a gathered copy of the admitted
+    // rows: `compact` is a flat index over that copy (its resident arrays live in the z_ buffers, grow-only like any
+    // workspace; z_pos maps a row of the copy back to its row of the base).
+    needle_hip_index compact;
+    nh::DevBuf z_raw, z_op16, z_op32, z_cinit, z_pos, z_cnt;
     bool busy = false;
 };
 // Takes a free slot of `parent` (creating one, or waiting), refreshes its view of the parent's resident data (building

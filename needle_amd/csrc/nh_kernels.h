@@ -237,6 +237,16 @@ hipError_t launch_scatter_results(const uint32_t* d_idx, uint32_t n, uint32_t k,
 // 16-bit rows (F16 or Bf16 of src/indexing/float16.rs) widened exactly to f32 (prep.hip)
 hipError_t launch_half_widen(const uint16_t* d_in, uint64_t total, bool bf16, float* d_out, hipStream_t stream);
 // per-search accumulator seeds with dead rows (deleted, filtered out, beyond n) at -inf (prep.hip)
+// Compaction of the rows a filtered search admits (prep.hip): per-block counts + total, ascending positions, gathered
+// rows (rows at or beyond `live` zero), hits renamed to base row numbers.
+uint32_t mask_blocks(uint32_t n);  // entries of d_block_counts for n rows
+hipError_t launch_mask_count(const uint32_t* d_valid, const uint32_t* d_filter, uint32_t n, uint32_t* d_block_counts, uint32_t* d_total,
+                             hipStream_t stream);
+hipError_t launch_mask_positions(const uint32_t* d_valid, const uint32_t* d_filter, uint32_t n, uint32_t* d_block_counts, uint32_t live,
+                                 uint32_t* d_pos, hipStream_t stream);
+hipError_t launch_gather_row_bytes(const void* d_src, const uint32_t* d_pos, uint32_t live, uint32_t rows, uint32_t n_src,
+                                   size_t row_bytes, void* d_dst, hipStream_t stream);
+hipError_t launch_map_ids(uint64_t* d_ids, uint64_t total, const uint32_t* d_pos, uint32_t live, hipStream_t stream);
 hipError_t launch_masked_seed(const float* d_seed, const uint32_t* d_valid, const uint32_t* d_filter, uint32_t n, uint32_t n_pad,
                               float* d_out, hipStream_t stream);
 hipError_t launch_fill_empty(uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, uint32_t q,

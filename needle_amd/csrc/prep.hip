@@ -310,4 +310,164 @@ hipError_t launch_masked_seed(const float* d_seed, const uint32_t* d_valid, cons
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Admitted rows of a filtered search, compacted: a search whose masks admit a small part of the base scans a gathered
+// copy of the admitted rows instead of the whole base (work proportional to the rows that can be returned).
+//   mask_count      per block of 256 mask words (8192 rows) the number of admitted rows; the total
+//   mask_offsets    exclusive sums of the block counts (one workgroup)
+//   mask_positions  the admitted row numbers in ascending order
+//   gather_words    rows of 4-byte words gathered through the positions; rows at or beyond `live` are zero
+//   map_ids         hits of the compacted search renamed to row numbers of the base
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t MASK_BLOCK_WORDS = 256;
+
+__device__ inline uint32_t admitted_word(const uint32_t* __restrict__ valid, const uint32_t* __restrict__ filter, uint32_t w,
+                                         uint32_t n) {
+    const uint32_t words = (n + 31u) / 32u;
+    if (w >= words) return 0u;
+    uint32_t m = 0xffffffffu;
+    if (valid) m &= valid[w];
+    if (filter) m &= filter[w];
+    if (w == words - 1 && (n & 31u)) m &= (1u << (n & 31u)) - 1u;  // bits beyond the last row name no row
+    return m;
+}
+
+__global__ __launch_bounds__(256) void mask_count_kernel(const uint32_t* __restrict__ valid, const uint32_t* __restrict__ filter,
+                                                         uint32_t n, uint32_t* __restrict__ block_counts,
+                                                         uint32_t* __restrict__ total) {
+    __shared__ uint32_t part[4];
+    const uint32_t w = blockIdx.x * MASK_BLOCK_WORDS + threadIdx.x;
+    uint32_t c = (uint32_t)__builtin_popcount(admitted_word(valid, filter, w, n));
+#pragma unroll
+    for (int off = 32; off; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t s = part[0] + part[1] + part[2] + part[3];
+        block_counts[blockIdx.x] = s;
+        if (s) atomicAdd(total, s);
+    }
+}
+
+__global__ __launch_bounds__(1024) void mask_offsets_kernel(uint32_t* __restrict__ block_counts, uint32_t n_blocks) {
+    // in place: counts -> exclusive sums; 1024 threads walk the blocks in pieces of 1024 with a running carry
+    __shared__ uint32_t wave_sum[16];
+    __shared__ uint32_t carry;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += 1024) {
+        const uint32_t b = b0 + t;
+        const uint32_t c = b < n_blocks ? block_counts[b] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, off);
+            if (lane >= (uint32_t)off) incl += v;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry;
+        for (uint32_t w = 0; w < wave; ++w) before += wave_sum[w];
+        if (b < n_blocks) block_counts[b] = before + incl - c;
+        __syncthreads();
+        if (t == 1023) carry = before + incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void mask_positions_kernel(const uint32_t* __restrict__ valid, const uint32_t* __restrict__ filter,
+                                                             uint32_t n, const uint32_t* __restrict__ block_offsets,
+                                                             uint32_t live, uint32_t* __restrict__ pos) {
+    __shared__ uint32_t wave_sum[4];
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t w = blockIdx.x * MASK_BLOCK_WORDS + t;
+    uint32_t m = admitted_word(valid, filter, w, n);
+    const uint32_t c = (uint32_t)__builtin_popcount(m);
+    uint32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= (uint32_t)off) incl += v;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    uint32_t at = block_offsets[blockIdx.x] + incl - c;
+    for (uint32_t v = 0; v < wave; ++v) at += wave_sum[v];
+    while (m) {
+        const uint32_t bit = (uint32_t)__builtin_ctz(m);
+        m &= m - 1;
+        if (at < live) pos[at] = w * 32u + bit;  // (at < live always: the counts come from the same masks)
+        ++at;
+    }
+}
+
+// dst[r][0 .. words) = src[pos[r]][0 .. words) for r < live, zeros for live <= r < rows; VEC 4-byte words per access
+template <typename V>
+__global__ __launch_bounds__(256) void gather_words_kernel(const V* __restrict__ src, const uint32_t* __restrict__ pos,
+                                                           uint32_t live, uint32_t rows, uint32_t n_src, uint32_t vecs_per_row,
+                                                           V* __restrict__ dst) {
+    const uint64_t total = (uint64_t)rows * vecs_per_row;
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (uint64_t)gridDim.x * 256) {
+        const uint32_t r = (uint32_t)(e / vecs_per_row), v = (uint32_t)(e % vecs_per_row);
+        V x{};
+        if (r < live) {
+            const uint32_t from = min(pos[r], n_src - 1);  // (a position is a row number of the base by construction)
+            x = src[(uint64_t)from * vecs_per_row + v];
+        }
+        dst[e] = x;
+    }
+}
+
+__global__ __launch_bounds__(256) void map_ids_kernel(uint64_t* __restrict__ ids, uint64_t total, const uint32_t* __restrict__ pos,
+                                                      uint32_t live) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const uint64_t id = ids[i];
+    if (id < (uint64_t)live) ids[i] = pos[id];  // padding entries (all ones) stay
+}
+
+hipError_t launch_mask_count(const uint32_t* d_valid, const uint32_t* d_filter, uint32_t n, uint32_t* d_block_counts, uint32_t* d_total,
+                             hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(d_total, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess || n == 0) return e;
+    const uint32_t words = (n + 31u) / 32u, blocks = (words + MASK_BLOCK_WORDS - 1) / MASK_BLOCK_WORDS;
+    hipLaunchKernelGGL(mask_count_kernel, dim3(blocks), dim3(256), 0, stream, d_valid, d_filter, n, d_block_counts, d_total);
+    return hipGetLastError();
+}
+
+uint32_t mask_blocks(uint32_t n) { return ((n + 31u) / 32u + MASK_BLOCK_WORDS - 1) / MASK_BLOCK_WORDS; }
+
+hipError_t launch_mask_positions(const uint32_t* d_valid, const uint32_t* d_filter, uint32_t n, uint32_t* d_block_counts, uint32_t live,
+                                 uint32_t* d_pos, hipStream_t stream) {
+    if (n == 0 || live == 0) return hipSuccess;
+    const uint32_t blocks = mask_blocks(n);
+    hipLaunchKernelGGL(mask_offsets_kernel, dim3(1), dim3(1024), 0, stream, d_block_counts, blocks);
+    hipLaunchKernelGGL(mask_positions_kernel, dim3(blocks), dim3(256), 0, stream, d_valid, d_filter, n, d_block_counts, live, d_pos);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_row_bytes(const void* d_src, const uint32_t* d_pos, uint32_t live, uint32_t rows, uint32_t n_src,
+                                   size_t row_bytes, void* d_dst, hipStream_t stream) {
+    if (rows == 0 || row_bytes == 0) return hipSuccess;
+    if (n_src == 0 || row_bytes % 4 != 0) return hipErrorInvalidValue;
+    const bool wide = row_bytes % 16 == 0 && ((uintptr_t)d_src % 16 == 0) && ((uintptr_t)d_dst % 16 == 0);
+    const uint32_t vecs = (uint32_t)(row_bytes / (wide ? 16 : 4));
+    const uint64_t total = (uint64_t)rows * vecs;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 1u << 20);
+    if (wide)
+        hipLaunchKernelGGL(gather_words_kernel<uint4>, dim3(grid), dim3(256), 0, stream, (const uint4*)d_src, d_pos, live, rows, n_src,
+                           vecs, (uint4*)d_dst);
+    else
+        hipLaunchKernelGGL(gather_words_kernel<uint32_t>, dim3(grid), dim3(256), 0, stream, (const uint32_t*)d_src, d_pos, live, rows,
+                           n_src, vecs, (uint32_t*)d_dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_map_ids(uint64_t* d_ids, uint64_t total, const uint32_t* d_pos, uint32_t live, hipStream_t stream) {
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(map_ids_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, d_ids, total, d_pos, live);
+    return hipGetLastError();
+}
+
 }  // namespace nh
