@@ -76,10 +76,12 @@ def test_random_flat_case(ctx, oracle, seed):
     tag = (metric, dim, n, nq, k, precision, kind, splits, valid is not None, filt is not None)
     if splits:
         ctx.set_tuning(splits=splits)
+    if filt is not None and rng.random() < 0.6:  # small bases too take the gathered copy of the admitted rows
+        ctx.set_tuning(compact_min_rows=1, compact_pct=int(rng.choice([50, 95])))
     try:
         _run_twice(oracle, ix, queries, base, k, m, precision, valid, filt, nq, tag)
     finally:
-        ctx.set_tuning(splits=0)
+        ctx.set_tuning(splits=0, compact_min_rows=0, compact_pct=0)
         ix.close()
 
 
