@@ -116,7 +116,11 @@ extern "C" needle_hip_status needle_hip_init(int device_id, needle_hip_ctx** out
 
 hipError_t nh::ensure_side_stream(needle_hip_ctx* c) {
     if (c->side) return hipSuccess;
-    hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    // lowest priority: what runs here (a wide, memory-heavy kernel) should fill the chip beside the short dependent kernels
+    // of the main stream, not stand in their way
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) destroy_side_stream(c);

@@ -257,7 +257,10 @@ __global__ __launch_bounds__(256) void ivf_regroup_count_kernel(RegroupBufs g) {
 // value_j(0 .. n_j - 1) into out_j[0 .. n_j]; part holds 3 x 1024 words
 template <typename F0, typename F1, typename F2>
 __device__ void rg_block_scan3(uint32_t n0, F0 v0, uint32_t* out0, uint32_t n1, F1 v1, uint32_t* out1, uint32_t n2, F2 v2,
-                               uint32_t* out2, uint32_t (*part)[1024], uint32_t (&total)[3]) {
+                               uint32_t* out2, uint32_t (*part)[1024], uint32_t (&total)[3], uint32_t* out0_scaled,
+                               uint32_t scale0, uint32_t& max0) {
+    // out0_scaled[i] = out0[i] * scale0 rides along with the first sum, max0 returns the thread's largest value_0: what
+    // the caller would otherwise re-read from memory behind the sums (a single workgroup is a chain of memory round trips)
     const uint32_t t = threadIdx.x;
     const uint32_t n[3] = {n0, n1, n2};
     uint32_t b[3], e[3], s[3] = {0u, 0u, 0u};
@@ -280,9 +283,9 @@ __device__ void rg_block_scan3(uint32_t n0, F0 v0, uint32_t* out0, uint32_t n1, 
             c2[u] = b[2] + u < e[2] ? v2(b[2] + u) : 0u;
         }
 #pragma unroll
-        for (uint32_t u = 0; u < RG_CACHE; ++u) { s[0] += c0[u]; s[1] += c1[u]; s[2] += c2[u]; }
+        for (uint32_t u = 0; u < RG_CACHE; ++u) { s[0] += c0[u]; s[1] += c1[u]; s[2] += c2[u]; max0 = max(max0, c0[u]); }
     } else {
-        for (uint32_t i = b[0]; i < e[0]; ++i) s[0] += v0(i);
+        for (uint32_t i = b[0]; i < e[0]; ++i) { const uint32_t v = v0(i); s[0] += v; max0 = max(max0, v); }
         for (uint32_t i = b[1]; i < e[1]; ++i) s[1] += v1(i);
         for (uint32_t i = b[2]; i < e[2]; ++i) s[2] += v2(i);
     }
@@ -307,16 +310,16 @@ __device__ void rg_block_scan3(uint32_t n0, F0 v0, uint32_t* out0, uint32_t n1, 
     if (cached) {
 #pragma unroll
         for (uint32_t u = 0; u < RG_CACHE; ++u) {
-            if (b[0] + u < e[0]) { out0[b[0] + u] = acc[0]; acc[0] += c0[u]; }
+            if (b[0] + u < e[0]) { out0[b[0] + u] = acc[0]; out0_scaled[b[0] + u] = acc[0] * scale0; acc[0] += c0[u]; }
             if (b[1] + u < e[1]) { out1[b[1] + u] = acc[1]; acc[1] += c1[u]; }
             if (b[2] + u < e[2]) { out2[b[2] + u] = acc[2]; acc[2] += c2[u]; }
         }
     } else {
-        for (uint32_t i = b[0]; i < e[0]; ++i) { out0[i] = acc[0]; acc[0] += v0(i); }
+        for (uint32_t i = b[0]; i < e[0]; ++i) { out0[i] = acc[0]; out0_scaled[i] = acc[0] * scale0; acc[0] += v0(i); }
         for (uint32_t i = b[1]; i < e[1]; ++i) { out1[i] = acc[1]; acc[1] += v1(i); }
         for (uint32_t i = b[2]; i < e[2]; ++i) { out2[i] = acc[2]; acc[2] += v2(i); }
     }
-    if (t == 0) { out0[n0] = total[0]; out1[n1] = total[1]; out2[n2] = total[2]; }
+    if (t == 0) { out0[n0] = total[0]; out0_scaled[n0] = total[0] * scale0; out1[n1] = total[1]; out2[n2] = total[2]; }
     __syncthreads();
 }
 
@@ -327,16 +330,14 @@ __global__ __launch_bounds__(1024) void ivf_regroup_scan_kernel(RegroupBufs g) {
     __syncthreads();
     const uint32_t SL = 3 * g.nlist;
     uint32_t total[3];
+    uint32_t m = 0;
     rg_block_scan3(
         g.q, [&](uint32_t i) { return g.qlists[i]; }, g.lbase,
         SL, [&](uint32_t i) { return g.cnt[i]; }, g.pair_off,
         SL, [&](uint32_t i) {
             const uint32_t l = i % g.nlist, c = g.cnt[i];
             return (c == 0 || g.list_len[l] == 0) ? 0u : rg_runs(g, l) * ((c + g.item_queries - 1) / g.item_queries);
-        }, g.item_off, part, total);
-    for (uint32_t i = threadIdx.x; i <= g.q; i += 1024) g.lbase_dev[i] = g.lbase[i] * g.lpe;
-    uint32_t m = 0;
-    for (uint32_t i = threadIdx.x; i < g.q; i += 1024) m = max(m, g.qlists[i]);
+        }, g.item_off, part, total, g.lbase_dev, g.lpe, m);
     atomicMax(&most, m);
     __syncthreads();
     if (threadIdx.x == 0) {
