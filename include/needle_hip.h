@@ -118,7 +118,11 @@ typedef struct needle_search_params {
      * row may be returned), NULL = no filter.  Exact pre-filter semantics of
      * Collection::brute_force_search, src/collection/search_methods.rs:215-223,
      * and GpuAccelerator::prefiltered_batch_search, gpu/mod.rs:1033-1080.  Host
-     * pointer for needle_hip_batch_search, device pointer for the *_device form. */
+     * pointer for needle_hip_batch_search, device pointer for the *_device form.
+     * A flat index whose masks (deleted rows and this filter) admit at most half
+     * of its rows is searched over a gathered copy of the admitted rows -- the
+     * reference scores only matching rows, too -- with the same hits; the
+     * metrics count such searches (compacted_searches). */
     const uint32_t* filter_bitmask;
 } needle_search_params;
 
