@@ -136,3 +136,39 @@ def test_device_resident_filter_and_share_threshold(ctx, oracle):
     finally:
         ctx.set_tuning(reset=1)
         ix.close()
+
+
+def test_concurrent_filtered_searches_keep_their_own_gathered_rows(ctx, oracle):
+    """Four callers search one index at once, each under its own filter: every search slot gathers its own copy."""
+    import threading
+
+    import needle_amd as na
+
+    rng = np.random.default_rng(21)
+    n, d, nq, k = 90_000, 64, 50, 10
+    base = rng.standard_normal((n, d)).astype(F)
+    ix = na.FlatIndex(ctx, base, na.DistanceFunction.Euclidean)
+    jobs = []
+    for t in range(4):
+        queries = rng.standard_normal((nq, d)).astype(F)
+        filt = rng.random(n) < (0.01, 0.08, 0.3, 0.7)[t]
+        jobs.append((queries, filt, oracle.flat_batch_search(queries, base, k, int(na.DistanceFunction.Euclidean), filt=filt)))
+    errors = []
+
+    def worker(job):
+        queries, filt, want = job
+        try:
+            for _ in range(6):
+                _equal(want, ix.search(queries, k, precision="bf16", filter_mask=filt))
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ctx.reset_metrics()
+    threads = [threading.Thread(target=worker, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[0]
+    assert ctx.metrics()["compacted_searches"] == 18   # three of the four filters admit less than half of the rows
+    ix.close()
