@@ -198,7 +198,6 @@ extern "C" needle_hip_status needle_hip_set_tuning(needle_hip_ctx* c, const char
     else if (k == "ivf_no_seed") t.ivf_no_seed = u;
     else if (k == "ivf_seed_rows") t.ivf_seed_rows = u;
     else if (k == "ivf_split") t.ivf_split = u;
-    else if (k == "ivf_late_seed") t.ivf_late_seed = u;
     else if (k == "binary_two_scans") t.binary_two_scans = u;
     else if (k == "trace") g_trace = u != 0;
     else if (k == "poison") g_poison = u != 0;
@@ -1227,11 +1226,6 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
         HIP_TRY(launch_dense_select(pp, c->stream));
     } else {
         HIP_TRY(launch_merge_select(pp, c->stream));
-    }
-    if (ix->ev_selected) {  // a caller is waiting for the candidates (see needle_hip_index::ev_selected)
-        HIP_TRY(hipEventRecord(ix->ev_selected, c->stream));
-        ix->selected_recorded = pp.cand_scores != nullptr;
-        ix->selected_kprime = kprime;
     }
     // set_only (the probe step of an inverted-file search): the caller needs the k nearest rows as a set, so only the
     // candidates whose first-pass scores leave their membership open are re-scored

@@ -88,9 +88,7 @@ __device__ __forceinline__ void seed_load8(const uint16_t* p, float (&v)[8]) {
 template <typename T>  // rows: the f32 rows, or their bf16 copy (row stride ld elements)
 __global__ __launch_bounds__(256) void ivf_seed_tau_kernel(const float* __restrict__ queries, const T* __restrict__ rows, uint32_t ld,
                                                            uint32_t sample_rows, const float* __restrict__ cinit, const uint32_t* __restrict__ probe,
-                                                           const uint32_t* __restrict__ probe_n, uint32_t np,
-                                                           const uint32_t* __restrict__ cand_ids, const float* __restrict__ cand_scores,
-                                                           const uint32_t* __restrict__ cand_n, uint32_t cand_ld, uint32_t nlist,
+                                                           const uint32_t* __restrict__ probe_n, uint32_t np, uint32_t nlist,
                                                            const uint32_t* __restrict__ list_pos,
                                                            const uint32_t* __restrict__ list_len,
                                                            const uint32_t* __restrict__ pos2id, const uint32_t* __restrict__ valid,
@@ -102,41 +100,9 @@ __global__ __launch_bounds__(256) void ivf_seed_tau_kernel(const float* __restri
     const uint32_t q = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x == 0) n_live = 0;
     ord[threadIdx.x] = 0u;
-    // Which list is sampled does not matter for correctness (any kseed live rows give a valid threshold); the nearest one
-    // gives the tightest.  With the coarse step's CANDIDATES at hand (cand_ids: list numbers with their first-pass scores,
-    // at most one per thread) the best-scoring one is taken, which lets this kernel run beside the coarse step's exact
-    // re-scoring instead of behind it; otherwise the first entry of the finished probe list.
-    __shared__ uint32_t s_best[4];
-    bool have = false;
-    uint32_t l = 0;
-    if (cand_ids) {
-        const uint32_t nc = min(cand_n[q], min(cand_ld, (uint32_t)blockDim.x));
-        uint32_t key = 0, who = 0;  // (score ordinal, list) of this thread's candidate; 0: none
-        if (threadIdx.x < nc) {
-            key = max(nh::f2ord(cand_scores[(uint64_t)q * cand_ld + threadIdx.x]), 1u);
-            who = cand_ids[(uint64_t)q * cand_ld + threadIdx.x];
-        }
-        uint32_t best = key;
-#pragma unroll
-        for (int off = 32; off; off >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, off));
-        const uint64_t holders = __builtin_amdgcn_ballot_w64(key == best && key != 0u);
-        if (lane == 0) s_best[wave] = best;
-        __syncthreads();
-        const uint32_t top = max(max(s_best[0], s_best[1]), max(s_best[2], s_best[3]));
-        __syncthreads();
-        // the first lane of the first wave holding the top score names the list
-        const uint32_t named = holders ? (uint32_t)__builtin_amdgcn_readlane((int)who, (int)__builtin_ctzll(holders)) : 0u;
-        if (lane == 0) s_best[wave] = (top != 0u && best == top && holders) ? (0x80000000u | named) : 0u;
-        __syncthreads();
-        for (int w = 3; w >= 0; --w)
-            if (s_best[w] & 0x80000000u) { have = true; l = s_best[w] & 0x7fffffffu; }
-        l = min(l, nlist - 1);
-    } else {
-        __syncthreads();
-        have = probe_n[q] > 0;
-        if (have) l = min(probe[(uint64_t)q * np], nlist - 1);
-    }
-    if (have) {  // block-uniform
+    __syncthreads();
+    if (probe_n[q] > 0) {  // block-uniform
+        const uint32_t l = min(probe[(uint64_t)q * np], nlist - 1);
         const uint32_t p0 = list_pos[l], len = min(list_len[l], min(sample_rows, IVF_SEED_ROWS));
         const float* qv = queries + (uint64_t)q * dim;
         // every wave scores a quarter of the sample (the steps of the scoring loop are serial: an even split keeps the
@@ -634,15 +600,10 @@ __global__ __launch_bounds__(256) void ivf_gather_probe_kernel(const uint32_t* _
 // for the device; h_flagged[0] (host) receives the number of queries the bound check left open once the caller has
 // synchronised the stream (their indices: ix->w_flagged).  shared_* : the bf16 query operand, |q|^2 and rounding errors
 // the coarse step prepared for the same queries (null: prepared here).
-// The coarse step's candidates (list numbers with first-pass scores, rows of `ld` entries), selected but not yet
-// re-scored when c->ev_fork fires: what lets the threshold sample start before the probe lists are final.
-struct EarlySeed { const uint32_t* cand_ids; const float* cand_scores; const uint32_t* cand_n; uint32_t ld; };
-
 static needle_hip_status ivf_scan_probed(needle_hip_index* ix, const float* d_queries, uint32_t q, uint32_t k, uint32_t np, bool bf16,
                                          const uint32_t* d_filter, const uint32_t* d_probe, const uint32_t* d_probe_n,
                                          uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, const void* shared_qop,
-                                         const double* shared_qn2, const float* shared_qerr, uint32_t* h_flagged,
-                                         const EarlySeed* early = nullptr) {
+                                         const double* shared_qn2, const float* shared_qerr, uint32_t* h_flagged) {
     needle_hip_ctx* c = ix->ctx;
     const bool pq = ix->pq_m != 0;
     const int scan_precision = bf16 ? NEEDLE_PRECISION_BF16 : NEEDLE_PRECISION_FP32;
@@ -707,9 +668,8 @@ static needle_hip_status ivf_scan_probed(needle_hip_index* ix, const float* d_qu
     rg.items = ix->v_items.as<IvfItem>();
     // Fork: the regrouping (four short kernels, one of them a single workgroup) stays on the search's stream; the query
     // operand, the masked seeds and the threshold sample need only the probe lists and run beside it on the side stream.
-    // (`early`: the fork event was recorded inside the coarse step, behind its candidate selection)
     HIP_TRY(ensure_side_stream(c));
-    if (!early) HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     hipLaunchKernelGGL(ivf_regroup_count_kernel, dim3((q + 255) / 256), dim3(256), 0, c->stream, rg);
@@ -790,16 +750,12 @@ static needle_hip_status ivf_scan_probed(needle_hip_index* ix, const float* d_qu
         if (c->tune.ivf_seed_rows) sample_rows = std::min<uint32_t>(c->tune.ivf_seed_rows, IVF_SEED_ROWS);
         if (bf16)
             hipLaunchKernelGGL(ivf_seed_tau_kernel<uint16_t>, dim3(q), dim3(256), 0, c->side, d_queries, (const uint16_t*)ix->d_op_bf16,
-                               dpad, sample_rows, ix->d_cinit, d_probe, d_probe_n, np, early ? early->cand_ids : nullptr,
-                               early ? early->cand_scores : nullptr, early ? early->cand_n : nullptr, early ? early->ld : 0u, ix->nlist,
-                               ix->d_list_pos, ix->d_list_len, ix->d_pos2id, ix->d_valid, d_filter, ix->dim, sp.kseed, band,
-                               ix->w_tau0.as<float>());
+                               dpad, sample_rows, ix->d_cinit, d_probe, d_probe_n, np, ix->nlist, ix->d_list_pos, ix->d_list_len, ix->d_pos2id,
+                               ix->d_valid, d_filter, ix->dim, sp.kseed, band, ix->w_tau0.as<float>());
         else
             hipLaunchKernelGGL(ivf_seed_tau_kernel<float>, dim3(q), dim3(256), 0, c->side, d_queries, (const float*)ix->d_raw, ix->dim,
-                               sample_rows, ix->d_cinit, d_probe, d_probe_n, np, early ? early->cand_ids : nullptr,
-                               early ? early->cand_scores : nullptr, early ? early->cand_n : nullptr, early ? early->ld : 0u, ix->nlist,
-                               ix->d_list_pos, ix->d_list_len, ix->d_pos2id, ix->d_valid, d_filter, ix->dim, sp.kseed, band,
-                               ix->w_tau0.as<float>());
+                               sample_rows, ix->d_cinit, d_probe, d_probe_n, np, ix->nlist, ix->d_list_pos, ix->d_list_len, ix->d_pos2id,
+                               ix->d_valid, d_filter, ix->dim, sp.kseed, band, ix->w_tau0.as<float>());
     }
     HIP_TRY(hipGetLastError());
     // ---- join ----
@@ -892,16 +848,8 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     // The coarse step is enqueued and the search goes on behind it at once: whether the first-pass scores left some
     // query's probe set open is read at the ONE synchronisation at the end (no device -> host copy between the probe and
     // the merge); such queries -- none on typical data -- are then re-run with an exact coarse step.
+    ST_TRY(ivf_probe_device(ix, d_queries, q, np, true, /*defer=*/true));
     needle_hip_index* cent = ix->centroids;
-    HIP_TRY(ensure_side_stream(c));
-    cent->ev_selected = c->ev_fork;  // recorded behind the coarse step's candidate selection
-    cent->selected_recorded = false;
-    const needle_hip_status probed = ivf_probe_device(ix, d_queries, q, np, true, /*defer=*/true);
-    cent->ev_selected = nullptr;
-    ST_TRY(probed);
-    EarlySeed early{cent->w_cand.as<uint32_t>(), cent->w_cscore.as<float>(), cent->w_candn.as<uint32_t>(), cent->selected_kprime};
-    const bool use_early = cent->selected_recorded && !c->tune.ivf_late_seed && early.cand_ids && early.cand_scores && early.cand_n &&
-                           early.ld >= 1 && early.ld <= 256;
     // the coarse step's query operand (bf16, unnormalised: both steps rank by Euclidean distance) serves the list scan too
     const bool probe_bf16 = flat_scan_bf16_dpad(ix->dim) != 0 &&
                             choose_kprime(std::min(np, ix->nlist), NEEDLE_PRECISION_BF16) <= (uint32_t)KPRIME_MAX;
@@ -910,7 +858,7 @@ needle_hip_status nh::ivf_search_batch_device(needle_hip_index* ix, const float*
     uint32_t n_flagged = 0, n_probe_open = 0;
     ST_TRY(ivf_scan_probed(ix, d_queries, q, k, np, bf16, d_filter, ix->v_probe32.as<uint32_t>(), ix->v_probe_n.as<uint32_t>(), d_out_ids,
                            d_out_dists, d_out_counts, share ? cent->w_qop.p : nullptr, share ? cent->w_qn2.as<double>() : nullptr,
-                           share ? cent->w_qerr.as<float>() : nullptr, &n_flagged, use_early ? &early : nullptr));
+                           share ? cent->w_qerr.as<float>() : nullptr, &n_flagged));
     HIP_TRY(hipMemcpyAsync(&n_probe_open, cent->w_flagcnt.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->profiling) {

@@ -75,7 +75,6 @@ struct Tuning {
     int32_t pre_tiles = -1;      // tiles per slice the threshold pre-pass samples
     uint32_t kseed = 0;          // rank of the seeded threshold among the sampled group maxima
     float band = 0.0f;           // width of the threshold band in score uncertainties
-    uint32_t ivf_late_seed = 0;  // 1: the IVF threshold sample waits for the finished probe lists instead of the coarse candidates
     uint32_t no_compact = 0;     // 1: a filtered flat search never scans a gathered copy of the admitted rows
     uint32_t compact_pct = 0;    // largest admitted share (percent of the rows) that still takes the gathered copy (0: 50)
     uint32_t compact_min_rows = 0;  // smallest base that does (0: 65536 rows)
@@ -182,12 +181,6 @@ struct needle_hip_index {
     std::vector<nh::SearchSlot*> slots;
     bool is_view = false;
     nh::SearchSlot* slot = nullptr;  // a view: the search slot it belongs to
-    // A caller that wants to act as soon as this index's first-pass candidates are selected -- before their exact
-    // re-scoring -- sets ev_selected: the flat search records it behind its selection kernel and notes whether the
-    // candidates carry their scores (w_cand / w_cscore / w_candn, rows of selected_kprime entries).
-    hipEvent_t ev_selected = nullptr;
-    bool selected_recorded = false;
-    uint32_t selected_kprime = 0;
 };
 
 namespace nh {
