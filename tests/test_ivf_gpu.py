@@ -325,3 +325,36 @@ def test_probe_set_decided_by_scores(ctx, oracle, case):
     if case == "cluster200":
         assert ctx.metrics()["refined_queries"] > 0
     ix.close()
+
+
+def test_thresholds_come_from_rows_the_query_scans(ctx, oracle):
+    """nprobe = 1 and two centroids a rounding apart: a query's starting threshold may only be taken from rows of the
+    list it really probes.  The other list holds rows far nearer to the query -- a threshold sampled there (say, because a
+    reduced-precision score ranked that centroid first) would rule out every row the query goes on to scan."""
+    from needle_amd.ivf import IvfConfig, IvfIndex
+
+    rng = np.random.default_rng(77)
+    d, eps = 64, F(1e-3)
+    cents = np.zeros((2, d), dtype=F)
+    cents[1, 0] = eps                                      # the centroids differ by 1e-3 in one coordinate
+    near = np.zeros((300, d), dtype=F)                     # rows of list 0: five units from the queries
+    near[:, 0] = F(-1e-3)
+    near[:, 1] = F(5.0)
+    near += F(1e-4) * rng.standard_normal(near.shape).astype(F)
+    far = np.zeros((300, d), dtype=F)                      # rows of list 1: a hundred units away
+    far[:, 0] = F(100.0)
+    far += F(0.5) * rng.standard_normal(far.shape).astype(F)
+    base = np.concatenate([near, far]).astype(F)
+    queries = np.zeros((200, d), dtype=F)                  # on the line through the centroids, either side of the bisector:
+    queries[:, 0] = eps / F(2.0) + F(2e-6) * rng.choice([-1.0, 1.0], 200).astype(F)   # f32 tells the sides apart, bf16 scores do not
+    ix = IvfIndex(d, IvfConfig.new(2).with_nprobe(1), ctx=ctx)
+    ix.set_centroids(cents)
+    ix.add(range(base.shape[0]), base)
+    assign = oracle.ivf_assign(base, cents)
+    assert np.all(assign[:300] == 0) and np.all(assign[300:] == 1)
+    offsets, order = oracle.ivf_lists_from_assignment(assign, 2)
+    probed = np.array([oracle.ivf_probe(q, cents, 1)[0] for q in queries])
+    assert 40 < np.count_nonzero(probed == 1) < 160        # both sides occur
+    for precision in ("bf16", "fp32"):
+        _check_search(oracle, ix, base, cents, offsets, order, queries, 1, 5, precision=precision)
+    ix.close()
