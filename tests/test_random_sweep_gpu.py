@@ -95,3 +95,67 @@ def _run_twice(oracle, ix, queries, base, k, m, precision, valid, filt, nq, tag)
             assert np.array_equal(ids[i, :c], oi[i, :c]), (tag, i, ids[i, :c][:6], oi[i, :c][:6])
             assert np.array_equal(dists[i, :c].view(np.uint32), od[i, :c].view(np.uint32)), (tag, i)
             assert np.all(ids[i, c:] == U64MAX), (tag, i)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_resident_index_history(ctx, oracle, seed):
+    """A resident flat index lives through a random history -- appends of any size (host or device rows, with or without
+    masks), swap-removes, filtered and unfiltered searches in either precision -- and answers every search like the
+    oracle over the rows it holds at that moment."""
+    import torch
+
+    import needle_amd as na
+
+    rng = np.random.default_rng(9000 + seed + SEED_OFFSET)
+    metric = str(rng.choice(METRICS[:4]))
+    dim = int(rng.choice([5, 32, 96, 200]))
+    m = na.DistanceFunction[metric]
+
+    def draw(count):
+        x = rng.standard_normal((count, dim)).astype(F)
+        if metric == "CosineNormalized":
+            x = oracle.normalize_rows(x)
+        return x
+
+    rows = draw(int(rng.choice([0, 1, 300, 5000])))
+    valid = np.ones(rows.shape[0], dtype=bool)
+    ix = na.FlatIndex(ctx, rows, m, dim=dim)
+    try:
+        for step in range(int(rng.integers(6, 12))):
+            op = rng.random()
+            if op < 0.45 or rows.shape[0] < 20:
+                add = draw(int(rng.choice([1, 7, 130, 2000, 9000])))
+                if metric == "Cosine" and rng.random() < 0.3:
+                    add[rng.integers(0, add.shape[0])] *= F(1e-23)   # a norm f32 cannot square
+                mask = (rng.random(add.shape[0]) > 0.2) if rng.random() < 0.4 else None
+                src = torch.from_numpy(add).to("cuda:0") if rng.random() < 0.3 else add
+                ix.append(src, valid=mask)
+                rows = np.concatenate([rows, add])
+                valid = np.concatenate([valid, mask if mask is not None else np.ones(add.shape[0], dtype=bool)])
+            elif op < 0.6:
+                pos = int(rng.integers(0, rows.shape[0]))
+                ix.swap_remove(pos)
+                rows[pos], valid[pos] = rows[-1], valid[-1]
+                rows, valid = rows[:-1].copy(), valid[:-1].copy()
+            n = rows.shape[0]
+            assert len(ix) == n
+            nq, k = int(rng.choice([1, 9, 70])), int(rng.choice([1, 10, 60]))
+            queries = draw(nq)
+            if n > 3 and rng.random() < 0.5:
+                queries[0] = rows[int(rng.integers(0, n))]
+            filt = (rng.random(n) < rng.choice([0.03, 0.4, 0.9])) if rng.random() < 0.6 else None
+            if filt is not None and rng.random() < 0.7:
+                ctx.set_tuning(compact_min_rows=1)
+            precision = str(rng.choice(["bf16", "fp32"]))
+            tag = (seed, step, metric, dim, n, nq, k, precision, filt is not None)
+            oi, od, oc = oracle.flat_batch_search(queries, rows, k, int(m), valid=valid, filt=filt)
+            ids, dists, counts = ix.search(queries, k, precision=precision, filter_mask=filt)
+            ctx.set_tuning(compact_min_rows=0)
+            assert np.array_equal(counts, oc), tag
+            for i in range(nq):
+                c = int(oc[i])
+                assert np.array_equal(ids[i, :c], oi[i, :c]), (tag, i, ids[i, :c][:6], oi[i, :c][:6])
+                assert np.array_equal(dists[i, :c].view(np.uint32), od[i, :c].view(np.uint32)), (tag, i)
+    finally:
+        ctx.set_tuning(compact_min_rows=0)
+        ix.close()
