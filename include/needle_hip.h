@@ -87,12 +87,16 @@ typedef enum needle_metric {
  *                 (:489-496), the len % 8 tail added after the fold.  Cosine,
  *                 cosine-normalized, euclidean, dot product and manhattan
  *                 differ from DISTANCE_RS; hamming and chebyshev do not.  Flat
- *                 indexes, normalize and the operator-level calls. */
+ *                 indexes, normalize and the operator-level calls.
+ *   AVX512      : src/distance.rs:613-715, the same in a build with AVX-512
+ *                 enabled: sixteen lane sums, folded l_i + l_(i+8) and then as
+ *                 hsum_avx (:619-627), the len % 16 tail after the fold. */
 typedef enum needle_arith {
     NEEDLE_ARITH_DISTANCE_RS = 0,
     NEEDLE_ARITH_ACCEL_CHUNK4 = 1,
     NEEDLE_ARITH_SERVICE = 2,
-    NEEDLE_ARITH_AVX2 = 3
+    NEEDLE_ARITH_AVX2 = 3,
+    NEEDLE_ARITH_AVX512 = 4
 } needle_arith;
 
 /* Arithmetic of the candidate-generating first pass.  The returned ids and

@@ -750,9 +750,9 @@ __device__ inline double set_margin(const TauBand& band, uint32_t q) {
     return 2.0 * band_eps(band, q) + 2.05 * gam * s * s;
 }
 
-// AVX: the distances follow the order of a reference build with AVX2 enabled (exact_avx2: eight lane sums per
-// accumulator, kept across the dimension blocks; dc is then a multiple of 8).
-template <bool SET_ONLY, bool AVX = false>
+// AVX = 8 / 16: the distances follow the order of a reference build with AVX2 / AVX-512 enabled (exact_avx: that many
+// lane sums per accumulator, kept across the dimension blocks; dc is then a multiple of AVX).
+template <bool SET_ONLY, int AVX = 0>
 __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams p, uint32_t dc, uint32_t rcap, TauBand band) {
     extern __shared__ __attribute__((aligned(16))) float stage[];  // [dc] query block, then [rcap][dc + 4] row blocks
     __shared__ uint64_t skey[KPRIME_MAX];
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams
         RefAcc acc;
         const float zero = p.arith == NEEDLE_ARITH_ACCEL_CHUNK4 ? 0.0f : -0.0f;  // Rust's f32 Sum folds from -0.0
         acc.a = zero; acc.b = zero; acc.c = zero;
-        AvxAcc va, vq, vb;  // AVX: q.b (or the differences), q.q, b.b
+        AvxAccT<(AVX ? AVX : 8)> va, vq, vb;  // AVX: q.b (or the differences), q.q, b.b
         if (AVX) { avx_init(va); avx_init(vq); avx_init(vb); }
         float* qs = stage;
         float* rows = stage + dc;
@@ -963,7 +963,7 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams
 hipError_t launch_rescore_finalize(const PostParams& p, hipStream_t stream, const TauBand* set_only_band) {
     if (p.q == 0) return hipSuccess;
     if (set_only_band && (p.metric != NEEDLE_METRIC_EUCLIDEAN || !p.cand_scores || p.sq_codes || p.pq_codes || p.pos2id ||
-                          p.arith == NEEDLE_ARITH_AVX2))
+                          avx_lanes(p.arith) != 0))
         return hipErrorInvalidValue;
     // Rows staged at a time (rcap) and block of dimensions per stage (dc, a multiple of 4: groups of four never straddle
     // blocks).  A workgroup is a chain of dependent gathers, so what counts is how many of them a CU holds: the image is
@@ -976,11 +976,13 @@ hipError_t launch_rescore_finalize(const PostParams& p, hipStream_t stream, cons
     if (!set_only_band && p.q <= 1024) dc = 128u;
     if (p.tune_rs_cap >= 4 && p.tune_rs_cap <= p.kprime) rcap = p.tune_rs_cap;  // planning overrides
     if (p.tune_rs_dc / 4 * 4 >= 4 && p.tune_rs_dc <= 128) dc = p.tune_rs_dc / 4 * 4;
-    const bool avx = p.arith == NEEDLE_ARITH_AVX2 && !p.sq_codes && !p.pq_codes && avx2_metric(p.metric);
-    if (avx) dc = std::max<uint32_t>(8u, dc / 8 * 8);  // whole groups of eight lanes per block
+    const int avx = (!p.sq_codes && !p.pq_codes && avx2_metric(p.metric)) ? avx_lanes(p.arith) : 0;
+    if (avx) dc = std::max<uint32_t>(16u, dc / 16 * 16);  // whole groups of lanes per block
     const size_t lds = ((size_t)dc + (size_t)rcap * (dc + 4)) * sizeof(float);
-    if (avx && !set_only_band)
-        hipLaunchKernelGGL((rescore_finalize_kernel<false, true>), dim3(p.q), dim3(RS_THREADS), lds, stream, p, dc, rcap, TauBand{});
+    if (avx == 8 && !set_only_band)
+        hipLaunchKernelGGL((rescore_finalize_kernel<false, 8>), dim3(p.q), dim3(RS_THREADS), lds, stream, p, dc, rcap, TauBand{});
+    else if (avx == 16 && !set_only_band)
+        hipLaunchKernelGGL((rescore_finalize_kernel<false, 16>), dim3(p.q), dim3(RS_THREADS), lds, stream, p, dc, rcap, TauBand{});
     else if (set_only_band)
         hipLaunchKernelGGL(rescore_finalize_kernel<true>, dim3(p.q), dim3(RS_THREADS), lds, stream, p, dc, rcap, *set_only_band);
     else
@@ -1077,13 +1079,14 @@ __global__ __launch_bounds__(EX_ROWS) void exact_keys_kernel(ExactParams p) {
     for (int s = 0; s < EX_SLOTS; ++s) { acc[s].a = zero; acc[s].b = kind == RK_PQ_TABLE ? -0.0f : zero; acc[s].c = zero; }
 
     const uint32_t rows_here = min((uint32_t)EX_ROWS, p.n > row0 ? p.n - row0 : 0u);
-    // the AVX2-build order (eight lane sums per accumulator) is not staged: every thread walks its own row
-    const bool avx = p.arith == NEEDLE_ARITH_AVX2 && !sq8 && !pq && avx2_metric(p.metric);  // uniform over the grid
+    // the SIMD-build orders (8 or 16 lane sums per accumulator) are not staged: every thread walks its own row
+    const bool avx = avx_lanes(p.arith) && !sq8 && !pq && avx2_metric(p.metric);  // uniform over the grid
     float avx_d[EX_SLOTS];
     if (avx) {
 #pragma unroll
         for (int s = 0; s < EX_SLOTS; ++s)
-            avx_d[s] = live[s] ? exact_avx2(p.metric, p.query_raw + (uint64_t)qidx[s] * p.dim, p.base_raw + (uint64_t)i * p.dim, p.dim) : 0.0f;
+            avx_d[s] = live[s] ? exact_simd_build(p.arith, p.metric, p.query_raw + (uint64_t)qidx[s] * p.dim, p.base_raw + (uint64_t)i * p.dim, p.dim)
+                               : 0.0f;
     }
     for (uint32_t c0 = 0; !avx && c0 < p.dim; c0 += EX_DC) {
         const uint32_t len = min((uint32_t)EX_DC, p.dim - c0);
@@ -1367,12 +1370,13 @@ __global__ __launch_bounds__(256) void distance_matrix_kernel(const float* __res
     const uint32_t t = threadIdx.x, r = t & 63, g = t >> 6;
     const uint64_t row0 = (uint64_t)blockIdx.x * DM_ROWS;
     const uint32_t q0 = blockIdx.y * DM_Q;
-    if (arith == NEEDLE_ARITH_AVX2 && avx2_metric(metric)) {
-        // the AVX2-build order (eight lane sums per accumulator) is not staged: every thread walks its own row and queries
+    if (avx_lanes(arith) && avx2_metric(metric)) {
+        // the SIMD-build orders (8 or 16 lane sums per accumulator) are not staged: every thread walks its own row and queries
         if (row0 + r < n)
             for (int j = 0; j < 4; ++j) {
                 const uint32_t qi = q0 + g * 4 + j;
-                if (qi < nq) out[(uint64_t)qi * n + row0 + r] = exact_avx2(metric, queries + (uint64_t)qi * dim, base + (row0 + r) * dim, dim);
+                if (qi < nq)
+                    out[(uint64_t)qi * n + row0 + r] = exact_simd_build(arith, metric, queries + (uint64_t)qi * dim, base + (row0 + r) * dim, dim);
             }
         return;  // uniform over the workgroup
     }

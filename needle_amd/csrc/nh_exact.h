@@ -4,7 +4,7 @@
 // rounding per multiply and per add (the translation units are compiled with
 // -ffp-contract=off), IEEE-correct sqrt and divide
 // (-fhip-fp32-correctly-rounded-divide-sqrt), subnormals kept.  The one fused
-// operation is the explicit fma of the AVX2-build order (exact_avx2).
+// operation is the explicit fma of the SIMD-build orders (exact_avx).
 #pragma once
 #include "nh_common.h"
 
@@ -176,17 +176,21 @@ __device__ inline float exact_service(int metric, const float* __restrict__ q, c
     return 1.0f - (dot / den);
 }
 
-// ---- src/distance.rs:481-591: the arithmetic of a reference build with AVX2 enabled ----
-// Eight lane sums from +0.0; lane l folds elements l, l + 8, l + 16, ... with ONE rounding per element (a fused
-// multiply-add; Manhattan: a plain add of |a - b|); the lanes are folded as hsum_avx does (:489-496),
-// ((l0 + l4) + (l2 + l6)) + ((l1 + l5) + (l3 + l7)); the dim % 8 tail is then added to that result one product at a time
-// (multiply and add rounded separately).
+// ---- src/distance.rs:481-738: the arithmetic of a reference build with AVX2 or AVX-512 enabled ----
+// L lane sums from +0.0 (L = 8: AVX2, :505-591; L = 16: AVX-512, :636-715); lane l folds elements l, l + L, l + 2L, ...
+// with ONE rounding per element (a fused multiply-add; Manhattan: a plain add of |a - b|); the lanes are folded as
+// hsum_avx does (:489-496), ((l0 + l4) + (l2 + l6)) + ((l1 + l5) + (l3 + l7)) -- sixteen lanes first as l_i + l_(i+8)
+// (hsum_avx512, :619-627); the dim % L tail is then added to that result one product at a time (multiply and add
+// rounded separately).
 enum AvxOp { AVX_DOT = 0, AVX_L2 = 1, AVX_L1 = 2 };
-struct AvxAcc { float l[8]; float r; };  // lane sums; r: the folded sum, once the tail has begun
+template <int L>
+struct AvxAccT { float l[L]; float r; };  // lane sums; r: the folded sum, once the tail has begun
+using AvxAcc = AvxAccT<8>;
 
-__device__ inline void avx_init(AvxAcc& s) {
+template <int L>
+__device__ inline void avx_init(AvxAccT<L>& s) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s.l[j] = 0.0f;
+    for (int j = 0; j < L; ++j) s.l[j] = 0.0f;
     s.r = 0.0f;
 }
 __device__ inline float avx_hsum(const float (&l)[8]) {
@@ -194,14 +198,20 @@ __device__ inline float avx_hsum(const float (&l)[8]) {
     const float t0 = s0 + s2, t1 = s1 + s3;
     return t0 + t1;
 }
-// elements [i0, i1) of the two vectors, at x[0 ..] and y[0 ..]; i0 is a multiple of 8, i1 a multiple of 8 or dim
-template <int OP>
-__device__ inline void avx_accumulate(AvxAcc& s, const float* x, const float* y, uint32_t i0, uint32_t i1, uint32_t dim) {
-    const uint32_t vec_end = dim & ~7u;
-    uint32_t i = i0;
-    for (; i + 8 <= i1 && i + 8 <= vec_end; i += 8) {
+__device__ inline float avx_hsum(const float (&l)[16]) {
+    float h[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 8; ++j) h[j] = l[j] + l[j + 8];
+    return avx_hsum(h);
+}
+// elements [i0, i1) of the two vectors, at x[0 ..] and y[0 ..]; i0 is a multiple of L, i1 a multiple of L or dim
+template <int OP, int L>
+__device__ inline void avx_accumulate(AvxAccT<L>& s, const float* x, const float* y, uint32_t i0, uint32_t i1, uint32_t dim) {
+    const uint32_t vec_end = dim / L * L;
+    uint32_t i = i0;
+    for (; i + L <= i1 && i + L <= vec_end; i += L) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
             const float a = x[i - i0 + j], b = y[i - i0 + j];
             if (OP == AVX_DOT) {
                 s.l[j] = __builtin_fmaf(a, b, s.l[j]);
@@ -229,9 +239,12 @@ __device__ inline void avx_accumulate(AvxAcc& s, const float* x, const float* y,
         }
     }
 }
-__device__ inline float avx_finish(const AvxAcc& s, uint32_t dim) { return (dim & 7u) ? s.r : avx_hsum(s.l); }
+template <int L>
+__device__ inline float avx_finish(const AvxAccT<L>& s, uint32_t dim) { return (dim % L) ? s.r : avx_hsum(s.l); }
 
-// does the AVX2 build compute this metric differently from the scalar build?  (Hamming and Chebyshev have no SIMD form)
+// lanes of the SIMD build an arithmetic names (0: not one of them)
+__device__ __host__ inline int avx_lanes(int arith) { return arith == NEEDLE_ARITH_AVX2 ? 8 : (arith == NEEDLE_ARITH_AVX512 ? 16 : 0); }
+// does a SIMD build compute this metric differently from the scalar build?  (Hamming and Chebyshev have no SIMD form)
 __device__ __host__ inline bool avx2_metric(int metric) {
     return metric == NEEDLE_METRIC_COSINE || metric == NEEDLE_METRIC_COSINE_NORMALIZED || metric == NEEDLE_METRIC_EUCLIDEAN ||
            metric == NEEDLE_METRIC_DOT_PRODUCT || metric == NEEDLE_METRIC_MANHATTAN;
@@ -251,9 +264,10 @@ __device__ inline float avx2_distance(int metric, float a, float qq, float bb) {
     default: return a;                                      // Manhattan, :323-339
     }
 }
-__device__ inline float exact_avx2(int metric, const float* __restrict__ q, const float* __restrict__ b, uint32_t dim) {
+template <int L>
+__device__ inline float exact_avx(int metric, const float* __restrict__ q, const float* __restrict__ b, uint32_t dim) {
     if (!avx2_metric(metric)) return exact_rs(metric, q, b, dim);
-    AvxAcc s, sq, sb;
+    AvxAccT<L> s, sq, sb;
     avx_init(s); avx_init(sq); avx_init(sb);
     if (metric == NEEDLE_METRIC_EUCLIDEAN) avx_accumulate<AVX_L2>(s, q, b, 0, dim, dim);
     else if (metric == NEEDLE_METRIC_MANHATTAN) avx_accumulate<AVX_L1>(s, q, b, 0, dim, dim);
@@ -264,11 +278,18 @@ __device__ inline float exact_avx2(int metric, const float* __restrict__ q, cons
     }
     return avx2_distance(metric, avx_finish(s, dim), avx_finish(sq, dim), avx_finish(sb, dim));
 }
+__device__ inline float exact_avx2(int metric, const float* __restrict__ q, const float* __restrict__ b, uint32_t dim) {
+    return exact_avx<8>(metric, q, b, dim);
+}
+// arith: NEEDLE_ARITH_AVX2 or NEEDLE_ARITH_AVX512
+__device__ inline float exact_simd_build(int arith, int metric, const float* __restrict__ q, const float* __restrict__ b, uint32_t dim) {
+    return arith == NEEDLE_ARITH_AVX512 ? exact_avx<16>(metric, q, b, dim) : exact_avx<8>(metric, q, b, dim);
+}
 
 __device__ inline float exact_distance(int metric, int arith, const float* __restrict__ q,
                                        const float* __restrict__ b, uint32_t dim) {
     if (arith == NEEDLE_ARITH_SERVICE) return exact_service(metric, q, b, dim);
-    if (arith == NEEDLE_ARITH_AVX2) return exact_avx2(metric, q, b, dim);
+    if (avx_lanes(arith)) return exact_simd_build(arith, metric, q, b, dim);
     return arith == NEEDLE_ARITH_ACCEL_CHUNK4 ? exact_chunk4(metric, q, b, dim)
                                               : exact_rs(metric, q, b, dim);
 }

@@ -170,24 +170,77 @@ NDL_API float ndl_manhattan_avx2(const float *a, const float *b, size_t n) {
     return r;
 }
 
+/* ---- the same functions in a build with AVX-512 enabled, src/distance.rs:613-715: sixteen lane sums, folded
+ * lane i + lane i + 8 (hsum_avx512, :619-627) and then as hsum_avx; the len % 16 tail after the fold. ---- */
+static float avx512_hsum(const float *l) {
+    float h[8];
+    for (int j = 0; j < 8; ++j) h[j] = l[j] + l[j + 8];
+    return avx2_hsum(h);
+}
+
+/* dot_product_avx512, src/distance.rs:636-655. */
+NDL_API float ndl_dot_avx512(const float *a, const float *b, size_t n) {
+    float l[16] = {0.0f};
+    size_t chunks = n / 16;
+    for (size_t c = 0; c < chunks; ++c)
+        for (int j = 0; j < 16; ++j) l[j] = fmaf(a[c * 16 + j], b[c * 16 + j], l[j]);
+    float r = avx512_hsum(l);
+    for (size_t i = chunks * 16; i < n; ++i) {
+        float p = a[i] * b[i];
+        r = r + p;
+    }
+    return r;
+}
+
+/* euclidean_squared_avx512, src/distance.rs:664-685. */
+NDL_API float ndl_euclidean_squared_avx512(const float *a, const float *b, size_t n) {
+    float l[16] = {0.0f};
+    size_t chunks = n / 16;
+    for (size_t c = 0; c < chunks; ++c)
+        for (int j = 0; j < 16; ++j) {
+            float d = a[c * 16 + j] - b[c * 16 + j];
+            l[j] = fmaf(d, d, l[j]);
+        }
+    float r = avx512_hsum(l);
+    for (size_t i = chunks * 16; i < n; ++i) {
+        float d = a[i] - b[i];
+        float p = d * d;
+        r = r + p;
+    }
+    return r;
+}
+
+/* manhattan_avx512, src/distance.rs:694-715. */
+NDL_API float ndl_manhattan_avx512(const float *a, const float *b, size_t n) {
+    float l[16] = {0.0f};
+    size_t chunks = n / 16;
+    for (size_t c = 0; c < chunks; ++c)
+        for (int j = 0; j < 16; ++j) l[j] = l[j] + fabsf(a[c * 16 + j] - b[c * 16 + j]);
+    float r = avx512_hsum(l);
+    for (size_t i = chunks * 16; i < n; ++i) r = r + fabsf(a[i] - b[i]);
+    return r;
+}
+
 /* DistanceFunction::compute in that build: cosine (:153-164), cosine_normalized
  * (:193-196), euclidean (:203-228), dot product (:264-304) and manhattan
  * (:323-339) go through the AVX2 functions; hamming and chebyshev have no SIMD
  * form. */
-#define NDL_AVX2_ORDER 0x100 /* or-ed into a metric: that build's arithmetic */
-static float ndl_compute_avx2(int metric, const float *a, const float *b, size_t n) {
+#define NDL_AVX2_ORDER 0x100   /* or-ed into a metric: the AVX2 build's arithmetic */
+#define NDL_AVX512_ORDER 0x200 /* or-ed into a metric: the AVX-512 build's arithmetic */
+static float ndl_compute_avx2(int metric, const float *a, const float *b, size_t n, int wide) {
+    float (*dot)(const float *, const float *, size_t) = wide ? ndl_dot_avx512 : ndl_dot_avx2;
     switch (metric) {
     case NDL_COSINE: {
-        float dot = ndl_dot_avx2(a, b, n);
-        float na = sqrtf(ndl_dot_avx2(a, a, n));
-        float nb = sqrtf(ndl_dot_avx2(b, b, n));
+        float d = dot(a, b, n);
+        float na = sqrtf(dot(a, a, n));
+        float nb = sqrtf(dot(b, b, n));
         if (na == 0.0f || nb == 0.0f) return 1.0f;
-        return 1.0f - (dot / (na * nb));
+        return 1.0f - (d / (na * nb));
     }
-    case NDL_COSINE_NORMALIZED: return 1.0f - ndl_dot_avx2(a, b, n);
-    case NDL_EUCLIDEAN: return sqrtf(ndl_euclidean_squared_avx2(a, b, n));
-    case NDL_DOT_PRODUCT: return -ndl_dot_avx2(a, b, n);
-    case NDL_MANHATTAN: return ndl_manhattan_avx2(a, b, n);
+    case NDL_COSINE_NORMALIZED: return 1.0f - dot(a, b, n);
+    case NDL_EUCLIDEAN: return sqrtf(wide ? ndl_euclidean_squared_avx512(a, b, n) : ndl_euclidean_squared_avx2(a, b, n));
+    case NDL_DOT_PRODUCT: return -dot(a, b, n);
+    case NDL_MANHATTAN: return wide ? ndl_manhattan_avx512(a, b, n) : ndl_manhattan_avx2(a, b, n);
     case NDL_HAMMING: return ndl_hamming(a, b, n);
     case NDL_CHEBYSHEV: return ndl_chebyshev(a, b, n);
     default: return NAN;
@@ -196,6 +249,13 @@ static float ndl_compute_avx2(int metric, const float *a, const float *b, size_t
 
 /* normalize (:426-455) in that build: the norm from dot_product_avx2, the scaling
  * a multiply per element either way. */
+NDL_API void ndl_normalize_avx512(float *v, size_t n) {
+    float norm = sqrtf(ndl_dot_avx512(v, v, n));
+    if (norm > 0.0f) {
+        float inv = 1.0f / norm;
+        for (size_t i = 0; i < n; ++i) v[i] = v[i] * inv;
+    }
+}
 NDL_API void ndl_normalize_avx2(float *v, size_t n) {
     float norm = sqrtf(ndl_dot_avx2(v, v, n));
     if (norm > 0.0f) {
@@ -206,7 +266,8 @@ NDL_API void ndl_normalize_avx2(float *v, size_t n) {
 
 /* DistanceFunction::compute, src/distance.rs:93-103. */
 NDL_API float ndl_compute(int metric, const float *a, const float *b, size_t n) {
-    if (metric & NDL_AVX2_ORDER) return ndl_compute_avx2(metric & ~NDL_AVX2_ORDER, a, b, n);
+    if (metric & NDL_AVX512_ORDER) return ndl_compute_avx2(metric & ~NDL_AVX512_ORDER, a, b, n, 1);
+    if (metric & NDL_AVX2_ORDER) return ndl_compute_avx2(metric & ~NDL_AVX2_ORDER, a, b, n, 0);
     switch (metric) {
     case NDL_COSINE: return ndl_cosine(a, b, n);
     case NDL_COSINE_NORMALIZED: return ndl_cosine_normalized(a, b, n);

@@ -1,6 +1,6 @@
-"""NEEDLE_ARITH_AVX2 on the device: flat search, the distance operators and normalize report the bits a reference build
-with AVX2 enabled computes (src/distance.rs:481-591) -- checked against the oracle's restatement of that order, and seen
-to differ from the scalar build's bits."""
+"""NEEDLE_ARITH_AVX2 / NEEDLE_ARITH_AVX512 on the device: flat search, the distance operators and normalize report the
+bits a reference build with AVX2 / AVX-512 enabled computes (src/distance.rs:481-738) -- checked against the oracle's
+restatement of those orders, and seen to differ from the scalar build's bits."""
 import numpy as np
 import pytest
 
@@ -32,11 +32,19 @@ def _check(oracle, got, base, queries, k, code, valid=None):
         assert np.array_equal(_bits(dists[i, :c]), _bits(od[i, :c])), i
 
 
+def _build(oracle, name):
+    from needle_amd import _lib
+
+    return (_lib.ARITH_AVX2, oracle.AVX2_ORDER) if name == "avx2" else (_lib.ARITH_AVX512, oracle.AVX512_ORDER)
+
+
+@pytest.mark.parametrize("build", ["avx2", "avx512"])
 @pytest.mark.parametrize("metric", ["Cosine", "CosineNormalized", "Euclidean", "DotProduct", "Manhattan", "Hamming", "Chebyshev"])
 @pytest.mark.parametrize("dim", [7, 100, 384])
-def test_flat_search_reports_the_avx2_builds_bits(ctx, oracle, metric, dim):
+def test_flat_search_reports_the_simd_builds_bits(ctx, oracle, metric, dim, build):
     import needle_amd as na
-    from needle_amd import _lib
+
+    arith, order = _build(oracle, build)
 
     rng = np.random.default_rng(dim * 7 + len(metric))
     n, nq, k = 3000, 60, 10
@@ -52,8 +60,8 @@ def test_flat_search_reports_the_avx2_builds_bits(ctx, oracle, metric, dim):
     base[77] = 0.0                # a zero norm
     valid = rng.random(n) > 0.1
     m = na.DistanceFunction[metric]
-    code = int(m) | oracle.AVX2_ORDER
-    ix = na.FlatIndex(ctx, base, m, arith=_lib.ARITH_AVX2, valid=valid)
+    code = int(m) | order
+    ix = na.FlatIndex(ctx, base, m, arith=arith, valid=valid)
     for prec in ("bf16", "fp32"):
         _check(oracle, ix.search(queries, k, precision=prec), base, queries, k, code, valid=valid)
     _check(oracle, ix.search(queries[:8], 300), base, queries[:8], 300, code, valid=valid)  # beyond the candidate budget: the exact scan
@@ -79,30 +87,31 @@ def test_append_keeps_the_arithmetic(ctx, oracle):
     ix.close()
 
 
+@pytest.mark.parametrize("build", ["avx2", "avx512"])
 @pytest.mark.parametrize("dim", [5, 8, 33, 384])
-def test_operators_in_the_avx2_order(ctx, oracle, dim):
+def test_operators_in_the_simd_build_orders(ctx, oracle, dim, build):
     import needle_amd as na
-    from needle_amd import _lib
+
+    arith, av = _build(oracle, build)
 
     rng = np.random.default_rng(dim)
     q = rng.standard_normal((19, dim)).astype(F)
     b = rng.standard_normal((150, dim)).astype(F)
     b[4] = 0.0
-    av = oracle.AVX2_ORDER
     for metric in (na.DistanceFunction.Cosine, na.DistanceFunction.Euclidean, na.DistanceFunction.DotProduct,
                    na.DistanceFunction.Manhattan, na.DistanceFunction.Chebyshev):
-        got = ctx.distance_matrix(metric, q, b, _lib.ARITH_AVX2)
+        got = ctx.distance_matrix(metric, q, b, arith)
         want = np.array([[oracle.compute(int(metric) | av, qi, bi) for bi in b] for qi in q], dtype=F)
         assert np.array_equal(_bits(got), _bits(want)), metric
     for metric in (na.DistanceFunction.Cosine, na.DistanceFunction.Euclidean, na.DistanceFunction.DotProduct):
-        got = ctx.batch_distance(metric, q[0], b, _lib.ARITH_AVX2)
+        got = ctx.batch_distance(metric, q[0], b, arith)
         want = np.array([oracle.compute(int(metric) | av, q[0], bi) for bi in b], dtype=F)
         if metric == na.DistanceFunction.DotProduct:
             want = -want  # batch_dot_product reports the product itself
         assert np.array_equal(_bits(got), _bits(want)), metric
-    idx, val, cnt = ctx.multi_query_search(na.DistanceFunction.Euclidean, q, b, 6, _lib.ARITH_AVX2)
+    idx, val, cnt = ctx.multi_query_search(na.DistanceFunction.Euclidean, q, b, 6, arith)
     oi, od, oc = oracle.flat_batch_search(q, b, 6, 2 | av)
     assert np.array_equal(np.asarray(idx).astype(np.uint64), oi) and np.array_equal(_bits(val), _bits(od))
-    got = ctx.normalize(b, _lib.ARITH_AVX2)
-    want = np.stack([oracle.normalized(r, avx2=True) for r in b])
+    got = ctx.normalize(b, arith)
+    want = np.stack([oracle.normalized(r, avx2=build == "avx2", avx512=build == "avx512") for r in b])
     assert np.array_equal(_bits(got), _bits(want))

@@ -23,17 +23,19 @@ def _fma(a, b, c) -> np.float32:
 
 
 def _hsum(l):
+    if len(l) == 16:                                 # hsum_avx512 (:619-627): low and high 256-bit halves first
+        l = [F(l[j] + l[j + 8]) for j in range(8)]
     s = [F(l[j] + l[j + 4]) for j in range(4)]      # _mm_add_ps(low half, high half)
     t0, t1 = F(s[0] + s[2]), F(s[1] + s[3])          # + movehl
     return F(t0 + t1)                                # + shuffle(1)
 
 
-def _by_hand(kind, a, b):
+def _by_hand(kind, a, b, width=8):
     n = a.size
-    lanes = [F(0.0)] * 8
-    for c in range(n // 8):
-        for j in range(8):
-            x, y = a[c * 8 + j], b[c * 8 + j]
+    lanes = [F(0.0)] * width
+    for c in range(n // width):
+        for j in range(width):
+            x, y = a[c * width + j], b[c * width + j]
             if kind == "dot":
                 lanes[j] = _fma(x, y, lanes[j])
             elif kind == "l2":
@@ -42,7 +44,7 @@ def _by_hand(kind, a, b):
             else:
                 lanes[j] = F(lanes[j] + np.abs(F(x - y)))
     r = _hsum(lanes)
-    for i in range(n // 8 * 8, n):
+    for i in range(n // width * width, n):
         x, y = a[i], b[i]
         if kind == "dot":
             r = F(r + F(x * y))
@@ -58,7 +60,7 @@ def _bits(x):
     return int(np.array(x, dtype=F).view(np.uint32))
 
 
-@pytest.mark.parametrize("dim", [1, 7, 8, 9, 16, 100, 384])
+@pytest.mark.parametrize("dim", [1, 7, 8, 9, 15, 16, 17, 40, 100, 384])
 def test_oracle_follows_the_hand_computed_eight_lane_fold(oracle, dim):
     rng = np.random.default_rng(dim)
     for _ in range(3):
@@ -66,6 +68,9 @@ def test_oracle_follows_the_hand_computed_eight_lane_fold(oracle, dim):
         assert _bits(oracle.dot_avx2(a, b)) == _bits(_by_hand("dot", a, b))
         assert _bits(oracle.euclidean_squared_avx2(a, b)) == _bits(_by_hand("l2", a, b))
         assert _bits(oracle.manhattan_avx2(a, b)) == _bits(_by_hand("l1", a, b))
+        assert _bits(oracle.dot_avx512(a, b)) == _bits(_by_hand("dot", a, b, 16))
+        assert _bits(oracle.euclidean_squared_avx512(a, b)) == _bits(_by_hand("l2", a, b, 16))
+        assert _bits(oracle.manhattan_avx512(a, b)) == _bits(_by_hand("l1", a, b, 16))
 
 
 def test_fused_rounding_is_what_decides_a_lane():
@@ -88,6 +93,12 @@ def test_the_order_differs_from_the_scalar_build_on_a_gaussian_pair(oracle):
     assert differing >= 3  # cosine, euclidean, dot, ... on this pair
     for m in (5, 6):       # hamming, chebyshev: no SIMD form
         assert _bits(oracle.compute(m, a, b)) == _bits(oracle.compute(m | av, a, b))
+        assert _bits(oracle.compute(m, a, b)) == _bits(oracle.compute(m | oracle.AVX512_ORDER, a, b))
+    # the three builds are three different arithmetics (on some pair: the sums differ in their last bits only)
+    rng = np.random.default_rng(4)
+    pairs = [(rng.standard_normal(384).astype(F), rng.standard_normal(384).astype(F)) for _ in range(20)]
+    assert any(_bits(oracle.dot_avx2(x, y)) != _bits(oracle.dot_avx512(x, y)) for x, y in pairs)
+    assert any(_bits(oracle.dot(x, y)) != _bits(oracle.dot_avx512(x, y)) for x, y in pairs)
 
 
 def test_compute_composes_the_metric_from_the_lane_sums(oracle):
@@ -102,6 +113,11 @@ def test_compute_composes_the_metric_from_the_lane_sums(oracle):
         assert _bits(oracle.compute(2 | av, a, b)) == _bits(np.sqrt(F(oracle.euclidean_squared_avx2(a, b))))
         assert _bits(oracle.compute(3 | av, a, b)) == _bits(-dot)
         assert _bits(oracle.compute(4 | av, a, b)) == _bits(oracle.manhattan_avx2(a, b))
+        wide = oracle.AVX512_ORDER
+        dot, qq, bb = F(oracle.dot_avx512(a, b)), F(oracle.dot_avx512(a, a)), F(oracle.dot_avx512(b, b))
+        assert _bits(oracle.compute(0 | wide, a, b)) == _bits(F(F(1.0) - F(dot / F(np.sqrt(qq) * np.sqrt(bb)))))
+        assert _bits(oracle.compute(2 | wide, a, b)) == _bits(np.sqrt(F(oracle.euclidean_squared_avx512(a, b))))
+        assert _bits(oracle.compute(4 | wide, a, b)) == _bits(oracle.manhattan_avx512(a, b))
     z = np.zeros(16, dtype=F)
     assert oracle.compute(0 | av, z, rng.standard_normal(16).astype(F)) == 1.0  # zero norm (distance.rs:159-161)
 
