@@ -47,6 +47,7 @@ pub const NEEDLE_ARITH_ACCEL_CHUNK4: c_int = 1; // src/experimental/gpu/common.r
 pub const NEEDLE_ARITH_SERVICE: c_int = 2; // src/services/compute/gpu_kernels.rs:345-358 (operator-level calls only)
 pub const NEEDLE_ARITH_AVX2: c_int = 3; // src/distance.rs:481-591: what a build with AVX2 enabled computes
 pub const NEEDLE_ARITH_AVX512: c_int = 4; // src/distance.rs:613-715: what a build with AVX-512 enabled computes
+pub const NEEDLE_ARITH_NEON: c_int = 5; // src/distance.rs:741-834: what an aarch64 build computes
 
 // needle_precision: all three return the same ids and distances; BF16 is the fast first pass
 pub const NEEDLE_PRECISION_FP32: i32 = 0;

@@ -90,13 +90,18 @@ typedef enum needle_metric {
  *                 indexes, normalize and the operator-level calls.
  *   AVX512      : src/distance.rs:613-715, the same in a build with AVX-512
  *                 enabled: sixteen lane sums, folded l_i + l_(i+8) and then as
- *                 hsum_avx (:619-627), the len % 16 tail after the fold. */
+ *                 hsum_avx (:619-627), the len % 16 tail after the fold.
+ *   NEON        : src/distance.rs:741-834, what an aarch64 build computes (its
+ *                 only path there): four lanes of vfmaq_f32, folded by
+ *                 vaddvq_f32 -- (l0 + l1) + (l2 + l3) --, the len % 4 tail
+ *                 after the fold. */
 typedef enum needle_arith {
     NEEDLE_ARITH_DISTANCE_RS = 0,
     NEEDLE_ARITH_ACCEL_CHUNK4 = 1,
     NEEDLE_ARITH_SERVICE = 2,
     NEEDLE_ARITH_AVX2 = 3,
-    NEEDLE_ARITH_AVX512 = 4
+    NEEDLE_ARITH_AVX512 = 4,
+    NEEDLE_ARITH_NEON = 5
 } needle_arith;
 
 /* Arithmetic of the candidate-generating first pass.  The returned ids and

@@ -19,7 +19,7 @@ OK, ERR_DIMENSION_MISMATCH, ERR_INVALID_VECTOR, ERR_INVALID_ARGUMENT, ERR_OUT_OF
 # needle_precision
 PRECISION_FP32, PRECISION_BF16, PRECISION_EXACT_SCAN = range(3)
 # needle_arith
-ARITH_DISTANCE_RS, ARITH_ACCEL_CHUNK4, ARITH_SERVICE, ARITH_AVX2, ARITH_AVX512 = range(5)
+ARITH_DISTANCE_RS, ARITH_ACCEL_CHUNK4, ARITH_SERVICE, ARITH_AVX2, ARITH_AVX512, ARITH_NEON = range(6)
 
 #: every symbol include/needle_hip.h declares
 EXPORTS = (

@@ -498,7 +498,7 @@ static needle_hip_status flat_alloc(needle_hip_ctx* c, uint64_t n, uint32_t dim,
     if ((int)metric < 0 || (int)metric > NEEDLE_METRIC_CHEBYSHEV)
         return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "unknown metric %d", (int)metric);
     if (arith != NEEDLE_ARITH_DISTANCE_RS && arith != NEEDLE_ARITH_ACCEL_CHUNK4 && arith != NEEDLE_ARITH_AVX2 &&
-        arith != NEEDLE_ARITH_AVX512)
+        arith != NEEDLE_ARITH_AVX512 && arith != NEEDLE_ARITH_NEON)
         return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "unknown arithmetic %d", (int)arith);
     if (arith == NEEDLE_ARITH_ACCEL_CHUNK4 && metric != NEEDLE_METRIC_COSINE && metric != NEEDLE_METRIC_EUCLIDEAN &&
         metric != NEEDLE_METRIC_DOT_PRODUCT)
@@ -1231,7 +1231,7 @@ needle_hip_status nh::flat_search_batch_device(needle_hip_index* ix, const float
     // set_only (the probe step of an inverted-file search): the caller needs the k nearest rows as a set, so only the
     // candidates whose first-pass scores leave their membership open are re-scored
     const bool set_mode = set_only && dense && prune && bf16 && !sq8 && ix->kind == KIND_FLAT && ix->metric == NEEDLE_METRIC_EUCLIDEAN &&
-                          !tune.no_set_only && ix->arith != NEEDLE_ARITH_AVX2 && ix->arith != NEEDLE_ARITH_AVX512;
+                          !tune.no_set_only && ix->arith != NEEDLE_ARITH_AVX2 && ix->arith != NEEDLE_ARITH_AVX512 && ix->arith != NEEDLE_ARITH_NEON;
     if (prune && !set_mode) HIP_TRY(launch_prune_candidates(pp, band, c->stream));
     HIP_TRY(launch_rescore_finalize(pp, c->stream, set_mode ? &band : nullptr));
     if (defer_flagged) return NEEDLE_HIP_OK;  // (this pass's device time is then not added to the metrics)

@@ -750,7 +750,7 @@ __device__ inline double set_margin(const TauBand& band, uint32_t q) {
     return 2.0 * band_eps(band, q) + 2.05 * gam * s * s;
 }
 
-// AVX = 8 / 16: the distances follow the order of a reference build with AVX2 / AVX-512 enabled (exact_avx: that many
+// AVX = 8 / 16 / 4: the distances follow the order of a reference build with AVX2 / AVX-512 / NEON (exact_avx: that many
 // lane sums per accumulator, kept across the dimension blocks; dc is then a multiple of AVX).
 template <bool SET_ONLY, int AVX = 0>
 __global__ __launch_bounds__(RS_THREADS) void rescore_finalize_kernel(PostParams p, uint32_t dc, uint32_t rcap, TauBand band) {
@@ -983,6 +983,8 @@ hipError_t launch_rescore_finalize(const PostParams& p, hipStream_t stream, cons
         hipLaunchKernelGGL((rescore_finalize_kernel<false, 8>), dim3(p.q), dim3(RS_THREADS), lds, stream, p, dc, rcap, TauBand{});
     else if (avx == 16 && !set_only_band)
         hipLaunchKernelGGL((rescore_finalize_kernel<false, 16>), dim3(p.q), dim3(RS_THREADS), lds, stream, p, dc, rcap, TauBand{});
+    else if (avx == 4 && !set_only_band)
+        hipLaunchKernelGGL((rescore_finalize_kernel<false, 4>), dim3(p.q), dim3(RS_THREADS), lds, stream, p, dc, rcap, TauBand{});
     else if (set_only_band)
         hipLaunchKernelGGL(rescore_finalize_kernel<true>, dim3(p.q), dim3(RS_THREADS), lds, stream, p, dc, rcap, *set_only_band);
     else

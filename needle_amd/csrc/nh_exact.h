@@ -177,7 +177,7 @@ __device__ inline float exact_service(int metric, const float* __restrict__ q, c
 }
 
 // ---- src/distance.rs:481-738: the arithmetic of a reference build with AVX2 or AVX-512 enabled ----
-// L lane sums from +0.0 (L = 8: AVX2, :505-591; L = 16: AVX-512, :636-715); lane l folds elements l, l + L, l + 2L, ...
+// L lane sums from +0.0 (L = 8: AVX2, :505-591; L = 16: AVX-512, :636-715; L = 4: the aarch64 build's NEON, :741-834); lane l folds elements l, l + L, l + 2L, ...
 // with ONE rounding per element (a fused multiply-add; Manhattan: a plain add of |a - b|); the lanes are folded as
 // hsum_avx does (:489-496), ((l0 + l4) + (l2 + l6)) + ((l1 + l5) + (l3 + l7)) -- sixteen lanes first as l_i + l_(i+8)
 // (hsum_avx512, :619-627); the dim % L tail is then added to that result one product at a time (multiply and add
@@ -197,6 +197,11 @@ __device__ inline float avx_hsum(const float (&l)[8]) {
     const float s0 = l[0] + l[4], s1 = l[1] + l[5], s2 = l[2] + l[6], s3 = l[3] + l[7];
     const float t0 = s0 + s2, t1 = s1 + s3;
     return t0 + t1;
+}
+// vaddvq_f32 (NEON, four lanes): the pairwise reduction the intrinsic compiles to, FADDP twice: (l0 + l1) + (l2 + l3)
+__device__ inline float avx_hsum(const float (&l)[4]) {
+    const float s0 = l[0] + l[1], s1 = l[2] + l[3];
+    return s0 + s1;
 }
 __device__ inline float avx_hsum(const float (&l)[16]) {
     float h[8];
@@ -243,7 +248,9 @@ template <int L>
 __device__ inline float avx_finish(const AvxAccT<L>& s, uint32_t dim) { return (dim % L) ? s.r : avx_hsum(s.l); }
 
 // lanes of the SIMD build an arithmetic names (0: not one of them)
-__device__ __host__ inline int avx_lanes(int arith) { return arith == NEEDLE_ARITH_AVX2 ? 8 : (arith == NEEDLE_ARITH_AVX512 ? 16 : 0); }
+__device__ __host__ inline int avx_lanes(int arith) {
+    return arith == NEEDLE_ARITH_AVX2 ? 8 : (arith == NEEDLE_ARITH_AVX512 ? 16 : (arith == NEEDLE_ARITH_NEON ? 4 : 0));
+}
 // does a SIMD build compute this metric differently from the scalar build?  (Hamming and Chebyshev have no SIMD form)
 __device__ __host__ inline bool avx2_metric(int metric) {
     return metric == NEEDLE_METRIC_COSINE || metric == NEEDLE_METRIC_COSINE_NORMALIZED || metric == NEEDLE_METRIC_EUCLIDEAN ||
@@ -281,8 +288,10 @@ __device__ inline float exact_avx(int metric, const float* __restrict__ q, const
 __device__ inline float exact_avx2(int metric, const float* __restrict__ q, const float* __restrict__ b, uint32_t dim) {
     return exact_avx<8>(metric, q, b, dim);
 }
-// arith: NEEDLE_ARITH_AVX2 or NEEDLE_ARITH_AVX512
+// arith: NEEDLE_ARITH_AVX2, NEEDLE_ARITH_AVX512 or NEEDLE_ARITH_NEON (src/distance.rs:741-834: four lanes of vfmaq_f32,
+// folded by vaddvq_f32, the len % 4 tail after the fold)
 __device__ inline float exact_simd_build(int arith, int metric, const float* __restrict__ q, const float* __restrict__ b, uint32_t dim) {
+    if (arith == NEEDLE_ARITH_NEON) return exact_avx<4>(metric, q, b, dim);
     return arith == NEEDLE_ARITH_AVX512 ? exact_avx<16>(metric, q, b, dim) : exact_avx<8>(metric, q, b, dim);
 }
 

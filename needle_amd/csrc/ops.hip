@@ -24,13 +24,16 @@ __global__ __launch_bounds__(NZ_ROWS) void normalize_rows_kernel(float* __restri
     const uint64_t row0 = (uint64_t)blockIdx.x * NZ_ROWS;
     const uint32_t t = threadIdx.x;
     const uint32_t rows = (uint32_t)(n - row0 < (uint64_t)NZ_ROWS ? n - row0 : (uint64_t)NZ_ROWS);
-    const bool chunk4 = arith == NEEDLE_ARITH_ACCEL_CHUNK4, avx = arith == NEEDLE_ARITH_AVX2, avx16 = arith == NEEDLE_ARITH_AVX512;
+    const bool chunk4 = arith == NEEDLE_ARITH_ACCEL_CHUNK4, avx = arith == NEEDLE_ARITH_AVX2, avx16 = arith == NEEDLE_ARITH_AVX512,
+               neon = arith == NEEDLE_ARITH_NEON;
     const uint32_t dim4 = dim & ~3u;
     float sum = chunk4 ? 0.0f : -0.0f;
     AvxAcc vsum;
     AvxAccT<16> vsum16;
+    AvxAccT<4> vsum4;
     avx_init(vsum);
     avx_init(vsum16);
+    avx_init(vsum4);
     for (uint32_t c0 = 0; c0 < dim; c0 += NZ_DC) {
         const uint32_t w = dim - c0 < (uint32_t)NZ_DC ? dim - c0 : (uint32_t)NZ_DC;
         for (uint32_t e = t; e < (uint32_t)NZ_ROWS * NZ_DC; e += NZ_ROWS) {
@@ -43,6 +46,8 @@ __global__ __launch_bounds__(NZ_ROWS) void normalize_rows_kernel(float* __restri
                 avx_accumulate<AVX_DOT>(vsum, tile[t], tile[t], c0, c0 + w, dim);
             } else if (avx16) {
                 avx_accumulate<AVX_DOT>(vsum16, tile[t], tile[t], c0, c0 + w, dim);
+            } else if (neon) {
+                avx_accumulate<AVX_DOT>(vsum4, tile[t], tile[t], c0, c0 + w, dim);
             } else if (chunk4) {
                 uint32_t c = 0;
                 for (; c + 4 <= w && c0 + c + 4 <= dim4; c += 4) {
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(NZ_ROWS) void normalize_rows_kernel(float* __restri
         }
         __syncthreads();
     }
-    s_norm[t] = sqrtf(avx ? avx_finish(vsum, dim) : (avx16 ? avx_finish(vsum16, dim) : sum));
+    s_norm[t] = sqrtf(avx ? avx_finish(vsum, dim) : (avx16 ? avx_finish(vsum16, dim) : (neon ? avx_finish(vsum4, dim) : sum)));
     __syncthreads();
     for (uint64_t e = t; e < (uint64_t)rows * dim; e += NZ_ROWS) {
         const uint32_t r = (uint32_t)(e / dim);
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(NZ_ROWS) void normalize_rows_kernel(float* __restri
 
 static needle_hip_status check_arith(needle_arith arith) {
     if (arith != NEEDLE_ARITH_DISTANCE_RS && arith != NEEDLE_ARITH_ACCEL_CHUNK4 && arith != NEEDLE_ARITH_AVX2 &&
-        arith != NEEDLE_ARITH_AVX512)
+        arith != NEEDLE_ARITH_AVX512 && arith != NEEDLE_ARITH_NEON)
         return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "unknown arithmetic %d", (int)arith);
     return NEEDLE_HIP_OK;
 }
@@ -418,11 +423,12 @@ static needle_hip_status matrix_check_args(needle_hip_ctx* c, needle_metric metr
                                            uint32_t dim) {
     if (!c) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "ctx is null");
     if (arith != NEEDLE_ARITH_DISTANCE_RS && arith != NEEDLE_ARITH_ACCEL_CHUNK4 && arith != NEEDLE_ARITH_SERVICE &&
-        arith != NEEDLE_ARITH_AVX2 && arith != NEEDLE_ARITH_AVX512)
+        arith != NEEDLE_ARITH_AVX2 && arith != NEEDLE_ARITH_AVX512 && arith != NEEDLE_ARITH_NEON)
         return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "unknown arithmetic %d", (int)arith);
     if (metric < NEEDLE_METRIC_COSINE || metric > NEEDLE_METRIC_CHEBYSHEV)
         return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "unknown metric %d", (int)metric);
-    if (arith != NEEDLE_ARITH_DISTANCE_RS && arith != NEEDLE_ARITH_AVX2 && arith != NEEDLE_ARITH_AVX512 && metric != NEEDLE_METRIC_COSINE &&
+    if (arith != NEEDLE_ARITH_DISTANCE_RS && arith != NEEDLE_ARITH_AVX2 && arith != NEEDLE_ARITH_AVX512 && arith != NEEDLE_ARITH_NEON &&
+        metric != NEEDLE_METRIC_COSINE &&
         metric != NEEDLE_METRIC_EUCLIDEAN && metric != NEEDLE_METRIC_DOT_PRODUCT)
         return fail(NEEDLE_HIP_ERR_UNSUPPORTED, "this arithmetic covers cosine, euclidean and dot product only");
     if (q > 0 && n > 0 && dim == 0) return fail(NEEDLE_HIP_ERR_INVALID_ARGUMENT, "dim is 0");

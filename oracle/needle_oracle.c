@@ -221,12 +221,77 @@ NDL_API float ndl_manhattan_avx512(const float *a, const float *b, size_t n) {
     return r;
 }
 
+/* ---- the aarch64 build, src/distance.rs:741-834: four lanes of vfmaq_f32 (fused), folded by vaddvq_f32 -- the pairwise
+ * reduction that intrinsic compiles to, FADDP twice: (l0 + l1) + (l2 + l3) --, the len % 4 tail after the fold.  The
+ * fold order rests on the instruction's definition; no aarch64 run pins it here. ---- */
+NDL_API float ndl_dot_neon(const float *a, const float *b, size_t n) {
+    float l[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    size_t chunks = n / 4;
+    for (size_t c = 0; c < chunks; ++c)
+        for (int j = 0; j < 4; ++j) l[j] = fmaf(a[c * 4 + j], b[c * 4 + j], l[j]);
+    float s0 = l[0] + l[1], s1 = l[2] + l[3];
+    float r = s0 + s1;
+    for (size_t i = chunks * 4; i < n; ++i) {
+        float p = a[i] * b[i];
+        r = r + p;
+    }
+    return r;
+}
+
+NDL_API float ndl_euclidean_squared_neon(const float *a, const float *b, size_t n) {
+    float l[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    size_t chunks = n / 4;
+    for (size_t c = 0; c < chunks; ++c)
+        for (int j = 0; j < 4; ++j) {
+            float d = a[c * 4 + j] - b[c * 4 + j];
+            l[j] = fmaf(d, d, l[j]);
+        }
+    float s0 = l[0] + l[1], s1 = l[2] + l[3];
+    float r = s0 + s1;
+    for (size_t i = chunks * 4; i < n; ++i) {
+        float d = a[i] - b[i];
+        float p = d * d;
+        r = r + p;
+    }
+    return r;
+}
+
+NDL_API float ndl_manhattan_neon(const float *a, const float *b, size_t n) {
+    float l[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    size_t chunks = n / 4;
+    for (size_t c = 0; c < chunks; ++c)
+        for (int j = 0; j < 4; ++j) l[j] = l[j] + fabsf(a[c * 4 + j] - b[c * 4 + j]);
+    float s0 = l[0] + l[1], s1 = l[2] + l[3];
+    float r = s0 + s1;
+    for (size_t i = chunks * 4; i < n; ++i) r = r + fabsf(a[i] - b[i]);
+    return r;
+}
+
 /* DistanceFunction::compute in that build: cosine (:153-164), cosine_normalized
  * (:193-196), euclidean (:203-228), dot product (:264-304) and manhattan
  * (:323-339) go through the AVX2 functions; hamming and chebyshev have no SIMD
  * form. */
 #define NDL_AVX2_ORDER 0x100   /* or-ed into a metric: the AVX2 build's arithmetic */
 #define NDL_AVX512_ORDER 0x200 /* or-ed into a metric: the AVX-512 build's arithmetic */
+#define NDL_NEON_ORDER 0x400   /* or-ed into a metric: the aarch64 build's arithmetic */
+static float ndl_compute_neon(int metric, const float *a, const float *b, size_t n) {
+    switch (metric) {
+    case NDL_COSINE: {
+        float d = ndl_dot_neon(a, b, n);
+        float na = sqrtf(ndl_dot_neon(a, a, n));
+        float nb = sqrtf(ndl_dot_neon(b, b, n));
+        if (na == 0.0f || nb == 0.0f) return 1.0f;
+        return 1.0f - (d / (na * nb));
+    }
+    case NDL_COSINE_NORMALIZED: return 1.0f - ndl_dot_neon(a, b, n);
+    case NDL_EUCLIDEAN: return sqrtf(ndl_euclidean_squared_neon(a, b, n));
+    case NDL_DOT_PRODUCT: return -ndl_dot_neon(a, b, n);
+    case NDL_MANHATTAN: return ndl_manhattan_neon(a, b, n);
+    case NDL_HAMMING: return ndl_hamming(a, b, n);
+    case NDL_CHEBYSHEV: return ndl_chebyshev(a, b, n);
+    default: return NAN;
+    }
+}
 static float ndl_compute_avx2(int metric, const float *a, const float *b, size_t n, int wide) {
     float (*dot)(const float *, const float *, size_t) = wide ? ndl_dot_avx512 : ndl_dot_avx2;
     switch (metric) {
@@ -249,6 +314,13 @@ static float ndl_compute_avx2(int metric, const float *a, const float *b, size_t
 
 /* normalize (:426-455) in that build: the norm from dot_product_avx2, the scaling
  * a multiply per element either way. */
+NDL_API void ndl_normalize_neon(float *v, size_t n) {
+    float norm = sqrtf(ndl_dot_neon(v, v, n));
+    if (norm > 0.0f) {
+        float inv = 1.0f / norm;
+        for (size_t i = 0; i < n; ++i) v[i] = v[i] * inv;
+    }
+}
 NDL_API void ndl_normalize_avx512(float *v, size_t n) {
     float norm = sqrtf(ndl_dot_avx512(v, v, n));
     if (norm > 0.0f) {
@@ -266,6 +338,7 @@ NDL_API void ndl_normalize_avx2(float *v, size_t n) {
 
 /* DistanceFunction::compute, src/distance.rs:93-103. */
 NDL_API float ndl_compute(int metric, const float *a, const float *b, size_t n) {
+    if (metric & NDL_NEON_ORDER) return ndl_compute_neon(metric & ~NDL_NEON_ORDER, a, b, n);
     if (metric & NDL_AVX512_ORDER) return ndl_compute_avx2(metric & ~NDL_AVX512_ORDER, a, b, n, 1);
     if (metric & NDL_AVX2_ORDER) return ndl_compute_avx2(metric & ~NDL_AVX2_ORDER, a, b, n, 0);
     switch (metric) {

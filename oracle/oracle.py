@@ -50,7 +50,8 @@ def _declare(L: C.CDLL) -> None:
     for name in ("ndl_dot", "ndl_euclidean_squared", "ndl_euclidean", "ndl_cosine", "ndl_cosine_normalized",
                  "ndl_dot_distance", "ndl_manhattan", "ndl_hamming", "ndl_chebyshev", "ndl_dot_chunk4",
                  "ndl_euclidean_chunk4", "ndl_dot_avx2", "ndl_euclidean_squared_avx2", "ndl_manhattan_avx2",
-                 "ndl_dot_avx512", "ndl_euclidean_squared_avx512", "ndl_manhattan_avx512"):
+                 "ndl_dot_avx512", "ndl_euclidean_squared_avx512", "ndl_manhattan_avx512",
+                 "ndl_dot_neon", "ndl_euclidean_squared_neon", "ndl_manhattan_neon"):
         f = getattr(L, name)
         f.restype = C.c_float
         f.argtypes = [_f32p, _f32p, sz]
@@ -64,6 +65,8 @@ def _declare(L: C.CDLL) -> None:
     L.ndl_normalize_avx2.argtypes = [_f32p, sz]
     L.ndl_normalize_avx512.restype = None
     L.ndl_normalize_avx512.argtypes = [_f32p, sz]
+    L.ndl_normalize_neon.restype = None
+    L.ndl_normalize_neon.argtypes = [_f32p, sz]
     L.ndl_metric_from_str.restype = C.c_int
     L.ndl_metric_from_str.argtypes = [C.c_char_p]
     L.ndl_validate_vector.restype = C.c_int
@@ -234,6 +237,10 @@ AVX512_ORDER = 0x200  # the same for a build with AVX-512 enabled (src/distance.
 dot_avx512 = _pair("ndl_dot_avx512")
 euclidean_squared_avx512 = _pair("ndl_euclidean_squared_avx512")
 manhattan_avx512 = _pair("ndl_manhattan_avx512")
+NEON_ORDER = 0x400  # the aarch64 build (src/distance.rs:741-834)
+dot_neon = _pair("ndl_dot_neon")
+euclidean_squared_neon = _pair("ndl_euclidean_squared_neon")
+manhattan_neon = _pair("ndl_manhattan_neon")
 
 
 def cosine_chunk4_precomputed(a, b, a_norm: float) -> float:
@@ -241,9 +248,10 @@ def cosine_chunk4_precomputed(a, b, a_norm: float) -> float:
     return float(lib().ndl_cosine_chunk4_precomputed(_p(a, _f32p), _p(b, _f32p), a.size, C.c_float(a_norm)))
 
 
-def normalized(v, avx2: bool = False, avx512: bool = False) -> np.ndarray:
+def normalized(v, avx2: bool = False, avx512: bool = False, neon: bool = False) -> np.ndarray:
     out = _f32(v).copy()
-    f = lib().ndl_normalize_avx512 if avx512 else (lib().ndl_normalize_avx2 if avx2 else lib().ndl_normalize)
+    f = lib().ndl_normalize_neon if neon else (
+        lib().ndl_normalize_avx512 if avx512 else (lib().ndl_normalize_avx2 if avx2 else lib().ndl_normalize))
     f(_p(out, _f32p), out.size)
     return out
 

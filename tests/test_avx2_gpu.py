@@ -35,10 +35,11 @@ def _check(oracle, got, base, queries, k, code, valid=None):
 def _build(oracle, name):
     from needle_amd import _lib
 
-    return (_lib.ARITH_AVX2, oracle.AVX2_ORDER) if name == "avx2" else (_lib.ARITH_AVX512, oracle.AVX512_ORDER)
+    return {"avx2": (_lib.ARITH_AVX2, oracle.AVX2_ORDER), "avx512": (_lib.ARITH_AVX512, oracle.AVX512_ORDER),
+            "neon": (_lib.ARITH_NEON, oracle.NEON_ORDER)}[name]
 
 
-@pytest.mark.parametrize("build", ["avx2", "avx512"])
+@pytest.mark.parametrize("build", ["avx2", "avx512", "neon"])
 @pytest.mark.parametrize("metric", ["Cosine", "CosineNormalized", "Euclidean", "DotProduct", "Manhattan", "Hamming", "Chebyshev"])
 @pytest.mark.parametrize("dim", [7, 100, 384])
 def test_flat_search_reports_the_simd_builds_bits(ctx, oracle, metric, dim, build):
@@ -87,7 +88,7 @@ def test_append_keeps_the_arithmetic(ctx, oracle):
     ix.close()
 
 
-@pytest.mark.parametrize("build", ["avx2", "avx512"])
+@pytest.mark.parametrize("build", ["avx2", "avx512", "neon"])
 @pytest.mark.parametrize("dim", [5, 8, 33, 384])
 def test_operators_in_the_simd_build_orders(ctx, oracle, dim, build):
     import needle_amd as na
@@ -113,5 +114,5 @@ def test_operators_in_the_simd_build_orders(ctx, oracle, dim, build):
     oi, od, oc = oracle.flat_batch_search(q, b, 6, 2 | av)
     assert np.array_equal(np.asarray(idx).astype(np.uint64), oi) and np.array_equal(_bits(val), _bits(od))
     got = ctx.normalize(b, arith)
-    want = np.stack([oracle.normalized(r, avx2=build == "avx2", avx512=build == "avx512") for r in b])
+    want = np.stack([oracle.normalized(r, avx2=build == "avx2", avx512=build == "avx512", neon=build == "neon") for r in b])
     assert np.array_equal(_bits(got), _bits(want))

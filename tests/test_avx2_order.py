@@ -23,6 +23,8 @@ def _fma(a, b, c) -> np.float32:
 
 
 def _hsum(l):
+    if len(l) == 4:                                  # vaddvq_f32: FADDP twice
+        return F(F(l[0] + l[1]) + F(l[2] + l[3]))
     if len(l) == 16:                                 # hsum_avx512 (:619-627): low and high 256-bit halves first
         l = [F(l[j] + l[j + 8]) for j in range(8)]
     s = [F(l[j] + l[j + 4]) for j in range(4)]      # _mm_add_ps(low half, high half)
@@ -71,6 +73,9 @@ def test_oracle_follows_the_hand_computed_eight_lane_fold(oracle, dim):
         assert _bits(oracle.dot_avx512(a, b)) == _bits(_by_hand("dot", a, b, 16))
         assert _bits(oracle.euclidean_squared_avx512(a, b)) == _bits(_by_hand("l2", a, b, 16))
         assert _bits(oracle.manhattan_avx512(a, b)) == _bits(_by_hand("l1", a, b, 16))
+        assert _bits(oracle.dot_neon(a, b)) == _bits(_by_hand("dot", a, b, 4))
+        assert _bits(oracle.euclidean_squared_neon(a, b)) == _bits(_by_hand("l2", a, b, 4))
+        assert _bits(oracle.manhattan_neon(a, b)) == _bits(_by_hand("l1", a, b, 4))
 
 
 def test_fused_rounding_is_what_decides_a_lane():
@@ -99,6 +104,10 @@ def test_the_order_differs_from_the_scalar_build_on_a_gaussian_pair(oracle):
     pairs = [(rng.standard_normal(384).astype(F), rng.standard_normal(384).astype(F)) for _ in range(20)]
     assert any(_bits(oracle.dot_avx2(x, y)) != _bits(oracle.dot_avx512(x, y)) for x, y in pairs)
     assert any(_bits(oracle.dot(x, y)) != _bits(oracle.dot_avx512(x, y)) for x, y in pairs)
+    assert any(_bits(oracle.dot_neon(x, y)) != _bits(oracle.dot_avx2(x, y)) for x, y in pairs)
+    x, y = pairs[0]
+    assert _bits(oracle.compute(2 | oracle.NEON_ORDER, x, y)) == _bits(np.sqrt(F(oracle.euclidean_squared_neon(x, y))))
+    assert _bits(oracle.compute(5 | oracle.NEON_ORDER, x, y)) == _bits(oracle.compute(5, x, y))
 
 
 def test_compute_composes_the_metric_from_the_lane_sums(oracle):
