@@ -82,6 +82,8 @@ def parse(argv=None):
     ap.add_argument("--ivf-leg-seconds", type=float, default=420.0, help="N > 1: time limit of the row-sharded IVF leg")
     ap.add_argument("--parity-queries", type=int, default=16, help="N > 1: queries rank 0 checks against the oracle (0 = skip)")
     ap.add_argument("--paths", default=DEFAULT_PATHS, help="N = 1: other configurations folded into the line ('none' = skip)")
+    ap.add_argument("--no-scaling-reference", action="store_true",
+                    help="N > 1: do not let rank 0 also search the whole base on its own GPU (config.single_gpu_same_workload)")
     ap.add_argument("--hnsw-rows", type=int, default=100_000, help="rows of the CPU HNSW baseline in `paths` (sequential build)")
     ap.add_argument("--hnsw-seconds", type=float, default=150.0,
                     help="time budget of that build: it stops there and the baseline covers the rows that are in")
@@ -509,6 +511,30 @@ def run(args, be):
         del base
         if line is not None:
             line["paths"] = [leg]
+    if by_rows and world > 1 and not args.no_scaling_reference:
+        # The strong-scaling reference of THIS workload: rank 0 searches the whole base on its own GPU while the others
+        # wait (the N = 1 run of the contract measures the metric's 1M-row configuration, a different workload).
+        if rank == 0:
+            try:
+                full = be.rows(rows_total, args.dim, 42)
+                whole = be.flat_index(full, metric)
+                one = be.searcher(whole, args.precision, 0, False)
+                one(queries, args.k)
+                be.sync()
+                reps = max(2, min(args.steps, 5))
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    one(queries, args.k)
+                be.sync()
+                dt = (time.perf_counter() - t0) / reps
+                ref = {"n_gpus": 1, "value": round(args.queries / dt, 1), "unit": "queries/s", "ms_per_step": round(dt * 1e3, 3),
+                       "workload": f"the same {rows_total}x{args.dim} base and query batch on one GPU, measured by rank 0 in this run"}
+                whole.close()
+                del full
+            except Exception as e:  # noqa: BLE001
+                ref = {"error": f"{type(e).__name__}: {e}"}
+            line["config"]["single_gpu_same_workload"] = ref
+        be.barrier()
     return line
 
 
