@@ -57,38 +57,51 @@ needle_hip_status nh::pq_search_batch_device(needle_hip_index* ix, const float* 
         c->m.fallback_queries += q;
         return NEEDLE_HIP_OK;
     }
-    // Queries go through in chunks whose interleaved distance tables (1 KB per query and subspace) stay within 1 GB.
+    // Queries go through in chunks whose interleaved distance tables (1 KB per query and subspace, whole slices of 16
+    // subspaces) stay within 1 GB.
     const uint32_t m = ix->pq_m;
-    const uint32_t q_chunk = std::max<uint32_t>(PQ_QB, (uint32_t)std::min<uint64_t>(16384, (1ull << 30) / ((uint64_t)m * 1024)) / PQ_QB * PQ_QB);
-    const uint32_t cap = 2 * k + 64;
+    const uint32_t q_chunk = std::max<uint32_t>(
+        PQ_QB, (uint32_t)std::min<uint64_t>(16384, (1ull << 30) / ((uint64_t)round_up(m, (uint32_t)PQ_SG) * 1024)) / PQ_QB * PQ_QB);
+    // Room per list: a compaction (cut back to the k best, the list's own threshold) holds up the whole workgroup at its
+    // next barrier, so with seeded thresholds a list should seldom need one before the scan ends.
+    const uint32_t cap = std::max<uint32_t>(2 * k + 64, 320);
     for (uint32_t q0 = 0; q0 < q; q0 += q_chunk) {
         const uint32_t qc = std::min(q_chunk, q - q0);
+        // Row splits of the code matrix.  Workgroup ids go round the XCDs, and the workgroups an XCD runs at a time (one per
+        // CU) are the S splits of 32 / S query groups: S is a power of two up to the CUs of an XCD, bounded by whole blocks
+        // of rows per split and by the PQ_WAVES * S lists of k entries per query the merge kernel gathers in its LDS.  Among
+        // those the S whose rounds of workgroups cost the least (rounds x rows per split), the smallest on a tie: every
+        // list is workspace and one more cold start.
         const uint32_t groups = (qc + PQ_QB - 1) / PQ_QB;
-        // Slices of the code matrix: a few whole blocks of rows each, PQ_WAVES * S lists of k entries per query within the
-        // merge kernel's LDS, and S * groups workgroups filling the chip in whole rounds (the smallest S that wastes
-        // less than a tenth of the last round, else the best found).
+        const uint32_t xcd_slots = std::max<uint32_t>(1, (uint32_t)c->n_cu / 8);
         uint32_t s_max = std::max<uint32_t>(1, n / (4 * pq_scan_block_rows()));
         s_max = std::min<uint32_t>(s_max, std::max<uint32_t>(1, 60000u / ((uint32_t)PQ_WAVES * k * (uint32_t)sizeof(uint64_t))));
         uint32_t S = 1;
-        double best = 0.0;
-        for (uint32_t s = 1; s <= s_max; ++s) {
-            const uint32_t wgs = s * groups, rounds = (wgs + (uint32_t)c->n_cu - 1) / (uint32_t)c->n_cu;
-            const double fill = (double)wgs / ((double)rounds * c->n_cu);
-            if (fill > best + 1e-9) { best = fill; S = s; }
-            if (fill >= 0.9) { S = s; break; }
+        double best_cost = 0.0;
+        for (uint32_t s = 1; s <= s_max && xcd_slots % s == 0; s *= 2) {
+            const uint32_t per_round = 8 * (xcd_slots / s), rounds = (groups + per_round - 1) / per_round;
+            const double cost = (double)rounds / s;
+            if (s == 1 || cost < best_cost * 0.999) { best_cost = cost; S = s; }
         }
-        const uint32_t rows_per_split = (n + S - 1) / S;
-        S = (n + rows_per_split - 1) / rows_per_split;
-        const uint32_t lists_per_q = PQ_WAVES * S;
+        if (c->tune.splits && c->tune.splits <= s_max && xcd_slots % c->tune.splits == 0) S = c->tune.splits;
+        const uint32_t rows_per_split = round_up((n + S - 1) / S, (uint32_t)PQ_SG);  // see PqScanParams
+        // Threshold seeding: every wave keeps a list of its own per query, and a list that starts empty takes (and keeps
+        // compacting) the first rows it meets.  A first launch scans a sample -- two blocks of rows at each of 8 places
+        // spread over the base -- and the k-th best score it finds per query is where every list of the real scan
+        // starts: a row scoring below it has k better rows in the sample alone.
+        // (planning override pre_tiles > 0: one block per place, and bases from twice the sample on -- for tests)
+        const bool forced = c->tune.pre_tiles > 0;
+        const uint32_t pre_S = 8, pre_rows = (forced ? 1 : 2) * pq_scan_block_rows();
+        const bool seed = n >= (forced ? 2 : 16) * pre_S * pre_rows && !(c->tune.debug & 2u) && xcd_slots % pre_S == 0;
+        const uint32_t lists_per_q = PQ_WAVES * S, pre_lists_per_q = PQ_WAVES * pre_S, max_lists = std::max(lists_per_q, seed ? pre_lists_per_q : 0u);
 
-        HIP_TRY(ix->w_pqtab.ensure((size_t)groups * m * 2 * 256 * 4 * sizeof(float)));
-        HIP_TRY(ix->w_lists.ensure((size_t)qc * lists_per_q * cap * sizeof(uint2)));
-        HIP_TRY(ix->w_lcnt.ensure((size_t)qc * lists_per_q * sizeof(uint32_t)));
+        HIP_TRY(ix->w_pqtab.ensure(pq_table_bytes(qc, m)));
+        HIP_TRY(ix->w_lists.ensure((size_t)qc * max_lists * cap * sizeof(uint2)));
+        HIP_TRY(ix->w_lcnt.ensure((size_t)qc * max_lists * sizeof(uint32_t)));
         HIP_TRY(ix->w_cand.ensure((size_t)qc * k * sizeof(uint32_t)));
         HIP_TRY(ix->w_scores.ensure((size_t)qc * k * sizeof(float)));
         HIP_TRY(ix->w_candn.ensure((size_t)qc * sizeof(uint32_t)));
         HIP_TRY(ix->w_tau.ensure((size_t)qc * sizeof(float)));
-        HIP_TRY(hipMemsetAsync(ix->w_lcnt.p, 0, (size_t)qc * lists_per_q * sizeof(uint32_t), c->stream));
 
         PqScanParams sp{};
         sp.codes_gm = ix->d_codes_gm;
@@ -98,13 +111,7 @@ needle_hip_status nh::pq_search_batch_device(needle_hip_index* ix, const float* 
         sp.lists = ix->w_lists.as<uint2>();
         sp.list_counts = ix->w_lcnt.as<uint32_t>();
         sp.n = n; sp.m = m; sp.n_sg = (m + PQ_SG - 1) / PQ_SG; sp.q = qc;
-        sp.n_splits = S; sp.rows_per_split = rows_per_split; sp.k = k; sp.cap = cap;
-        if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-        HIP_TRY(launch_pq_tables(d_queries + (size_t)q0 * ix->dim, ix->d_codebooks, qc, m, ix->pq_dsub, ix->dim, ix->w_pqtab.as<float>(),
-                                 c->stream));
-        HIP_TRY(launch_pq_scan(sp, c->stream));
-        if (c->profiling) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-
+        sp.k = k; sp.cap = cap; sp.xcd_slots = xcd_slots; sp.dev = c->tune.debug & (1u | 256u | 512u);
         PostParams pp{};
         pp.lists = sp.lists;
         pp.list_counts = sp.list_counts;
@@ -115,7 +122,25 @@ needle_hip_status nh::pq_search_batch_device(needle_hip_index* ix, const float* 
         pp.out_ids = d_out_ids + (size_t)q0 * k;
         pp.out_dists = d_out_dists + (size_t)q0 * k;
         pp.out_counts = d_out_counts + q0;
-        pp.q = qc; pp.n = n; pp.dim = ix->dim; pp.k = k; pp.kprime = k; pp.cap = cap; pp.n_splits = lists_per_q;
+        pp.q = qc; pp.n = n; pp.dim = ix->dim; pp.k = k; pp.kprime = k; pp.cap = cap;
+
+        if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        HIP_TRY(launch_pq_tables(d_queries + (size_t)q0 * ix->dim, ix->d_codebooks, qc, m, ix->pq_dsub, ix->dim, ix->w_pqtab.as<float>(),
+                                 c->stream));
+        if (seed) {
+            HIP_TRY(hipMemsetAsync(ix->w_lcnt.p, 0, (size_t)qc * pre_lists_per_q * sizeof(uint32_t), c->stream));
+            sp.n_splits = pre_S; sp.rows_per_split = pre_rows; sp.split_stride = n / pre_S / PQ_SG * PQ_SG; sp.tau_seed = nullptr;
+            HIP_TRY(launch_pq_scan(sp, c->stream));
+            pp.n_splits = pre_lists_per_q;
+            HIP_TRY(launch_merge_select(pp, c->stream));  // tau_star: the k-th best score of the sample (-inf: fewer than k live rows)
+        }
+        HIP_TRY(hipMemsetAsync(ix->w_lcnt.p, 0, (size_t)qc * lists_per_q * sizeof(uint32_t), c->stream));
+        sp.n_splits = S; sp.rows_per_split = rows_per_split; sp.split_stride = rows_per_split;
+        sp.tau_seed = seed ? ix->w_tau.as<float>() : nullptr;
+        HIP_TRY(launch_pq_scan(sp, c->stream));
+        if (c->profiling) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+
+        pp.n_splits = lists_per_q;
         HIP_TRY(launch_merge_select(pp, c->stream));
         HIP_TRY(launch_emit_sorted(pp, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));

@@ -158,15 +158,22 @@ hipError_t launch_emit_sorted(const PostParams& p, hipStream_t stream);
 // ProductQuantizer table scan, src/indexing/quantization.rs:468-503: per query the distance table
 // [m][256] is built in LDS, every row's distance is the table sum in subspace order, then sqrt.
 struct PqScanParams {
-    const uint8_t* codes_gm;   // [ceil(m / 16)][n][16]: the codes of 16 subspaces of a row in one 16-byte read
-    const float* tables;       // [ceil(q / 8)][m][2][256][4]: distance tables of 8 queries interleaved (pq_tables_kernel)
+    const uint8_t* codes_gm;   // [ceil(m / 16)][n][16]: the codes of 16 subspaces of a row in one 16-byte read, rotated by row & 15
+    const float* tables;       // [ceil(q / 8)][ceil(m / 16)][256][2][16][4]: distance tables of 8 queries, one LDS image per slice
     const uint32_t* valid;
     const uint32_t* filter;
     uint2* lists;              // [q][n_splits * PQ_WAVES][cap]  (bits of -distance, row)
     uint32_t* list_counts;     // [q][n_splits * PQ_WAVES]
-    uint32_t n, m, n_sg, q, n_splits, rows_per_split, k, cap;
+    const float* tau_seed;     // [q] a score at least k live rows of the query reach (a sample's k-th best), or null
+    uint32_t n, m, n_sg, q, n_splits, rows_per_split, k, cap;  // split s scans rows_per_split rows from s * split_stride on
+    uint32_t split_stride;     // a multiple of 16
+    uint32_t xcd_slots;        // workgroups an XCD runs at a time (its CUs); a multiple of n_splits
+    uint32_t dev;              // timing experiments only (results are wrong): 1 no selection, 256 tables filled once, 512 no lookups
 };
-constexpr int PQ_WAVES = 12;   // waves per workgroup sharing the resident tables; one candidate list per wave and query
+#ifndef PQ_WAVES_N
+#define PQ_WAVES_N 12
+#endif
+constexpr int PQ_WAVES = PQ_WAVES_N;   // waves per workgroup sharing the resident tables; one candidate list per wave and query
 constexpr int PQ_QB = 8;       // queries per workgroup
 constexpr int PQ_SG = 16;      // subspaces per resident table slice
 hipError_t launch_pq_tables(const float* d_queries, const float* d_codebooks, uint32_t q, uint32_t m, uint32_t dsub, uint32_t dim,
@@ -174,6 +181,7 @@ hipError_t launch_pq_tables(const float* d_queries, const float* d_codebooks, ui
 hipError_t launch_pq_group_codes(const uint8_t* codes, uint64_t n, uint32_t m, uint8_t* out, hipStream_t stream);
 hipError_t launch_pq_scan(const PqScanParams& p, hipStream_t stream);
 uint32_t pq_scan_block_rows();
+size_t pq_table_bytes(uint32_t q, uint32_t m);  // of the tables launch_pq_tables writes for q queries
 
 // Exact scan (every row scored in the reference's scalar order): the path for
 // queries whose first-pass candidates fail the bound check, for the metrics with

@@ -87,6 +87,42 @@ def test_pq_masks_ties_and_edges(ctx, oracle):
     small.close()
 
 
+def test_pq_table_scan_seeded_thresholds(ctx, oracle):
+    """The table scan's lists start at the k-th best score of a sample of the rows (8 places spread over the base).  Forced on
+    a base small enough for the oracle: rows tying the seed, masks that empty most of the sample, a filter that leaves fewer
+    than k live rows in it, and the unseeded plan all give the oracle's answer."""
+    from needle_amd.quantization import PqIndex, ProductQuantizer
+
+    rng = np.random.default_rng(77)
+    n, dim, m, k = 90_000, 64, 8, 10
+    base = rng.standard_normal((n, dim)).astype(F)
+    opq = oracle.ProductQuantizer.train(base[:500], m, seed=2)
+    codes = opq.encode(base)
+    queries = rng.standard_normal((21, dim)).astype(F)
+    queries[0] = base[11]
+    # rows with the codes of row 11 inside the sampled blocks (ties with the seed itself) and far outside them
+    codes[[3, 4000, 11_300, 50_001, 89_999]] = codes[11]
+    valid = np.ones(n, dtype=bool)
+    valid[:4096:2] = False
+    valid[45_000:46_000] = False
+    few = np.zeros(n, dtype=bool)
+    few[[5, 60_000, 60_001, 75_123]] = True  # fewer than k admitted rows: no seed, every admitted row returned
+    sparse = rng.random(n) < 0.02
+    ix = PqIndex(ctx, ProductQuantizer(opq.codebooks), codes, valid=valid)
+    try:
+        for tune in (dict(pre_tiles=1), dict(pre_tiles=1, splits=4), dict(debug=2)):
+            ctx.set_tuning(reset=1)
+            ctx.set_tuning(**tune)
+            _cmp(ix.search(queries, k), opq.batch_search(queries, codes, k, valid=valid))
+            _cmp(ix.search(queries, 1), opq.batch_search(queries, codes, 1, valid=valid))
+            _cmp(ix.search(queries, 100), opq.batch_search(queries, codes, 100, valid=valid))
+            _cmp(ix.search(queries, k, filter_mask=few), opq.batch_search(queries, codes, k, valid=valid & few))
+            _cmp(ix.search(queries, k, filter_mask=sparse), opq.batch_search(queries, codes, k, valid=valid & sparse))
+    finally:
+        ctx.set_tuning(reset=1)
+        ix.close()
+
+
 @pytest.mark.parametrize("shape", [(6000, 32, 10), (30000, 100, 10), (20000, 384, 10), (900, 7, 3)])
 def test_sq8_asymmetric_scan(ctx, oracle, shape):
     from needle_amd.quantization import ScalarQuantizer, Sq8Index

@@ -404,7 +404,7 @@ def pq_case(ctx, dev, n, dim, m_sub, nq, k, steps, oracle=None, build_timing=Tru
             byts = (-(-nq // qg)) * n * m_sub  # every query group streams the code matrix once
             lookups = nq * n * m_sub / sec
             # a lookup is an LDS gather: 16-byte reads fetch the entries of 4 queries, 256 B per clock and CU when no two lanes
-            # of a 16-lane phase share a four-bank slot (random codes: about three lanes do)
+            # of a 16-lane phase share a four-bank slot (the kernel's lane skew makes the slot the subspace: no conflicts)
             lds_peak = 256 * 64 * 2.4e9
             extra = {"first_pass": "f32 distance-table scan", "queries_per_workgroup": qg, "bytes_scanned": byts,
                      "GBps_over_whole_search": round(byts / sec / 1e9, 1),
@@ -414,7 +414,7 @@ def pq_case(ctx, dev, n, dim, m_sub, nq, k, steps, oracle=None, build_timing=Tru
                      "table_lookups_per_s": round(lookups / 1e12, 3),
                      "lds_gather": {"achieved_lookups_per_s": round(lookups / 1e12, 3), "conflict_free_peak": round(lds_peak / 1e12, 1),
                                     "unit": "1e12 lookups/s", "frac": round(lookups / lds_peak, 4),
-                                    "note": "the kernel is bound by the LDS gather, not by the code bytes"}}
+                                    "note": "conflict-free gather (lane skew); beside it the kernel issues 10 vector instructions per 8 lookups and refills its 128 KB of tables once per block of rows"}}
         if oracle is not None:
             s, ns = 6, 500_000
             small = na.quantization.PqIndex(ctx, pq, codes[:ns])
