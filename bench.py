@@ -15,11 +15,14 @@ IVF nlist 4096 / nprobe 32 over 1.25M x 384, SQ8 and PQ m=48 over 6.25M x 384), 
 object, parity sample and host-pointer rate, and the reference's HNSW restated on the CPU over a bounded sample.
 
 --gpus N > 1 (one rank per GPU: under torch.distributed.run, or started by this script itself when no launcher set
-WORLD_SIZE -- never a silent single-GPU run): the base -- by default 10M x 384 --
-is split into N contiguous row blocks, every GPU scans its block for ALL queries, the per-shard results
-travel in one RCCL all-gather and are merged on every rank (needle_hip_sharded_batch_search_device):
-strong scaling of one batch.  `--shard queries` is the opt-in alternative (every GPU holds the whole base
-and serves its own queries, no exchange).
+WORLD_SIZE -- never a silent single-GPU run): the base is split into N contiguous row blocks, every GPU scans its
+block for ALL queries, the per-shard results travel in one RCCL all-gather and are merged on every rank
+(needle_hip_sharded_batch_search_device): strong scaling of one batch.  `value` is measured on the SAME workload as at
+N = 1 (1M x 384, 10K queries), so the values of N = 1, 2, 4, 8 form one strong-scaling curve; the metric's 10M x 384
+base, split the same way, follows in the same run as `paths` entries (`flat10m_sharded`: exact flat; `ivf_sharded`:
+nlist 4096 / nprobe 32), each with the one-GPU time of its own workload measured by rank 0 beside it.  `--rows R`
+runs only an R-row base; `--shard queries` is the opt-in alternative (every GPU holds the whole base and serves its
+own queries, no exchange).
 
 NEEDLE_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks: ranks
 share devices, the one all-gather goes over gloo and the merge runs through needle_hip_merge_shard_slots_device.
@@ -69,7 +72,11 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=None,
-                    help="total base rows (default: 1M on one GPU, 10M split across N > 1 GPUs)")
+                    help="total base rows (default: 1M, split across the GPUs; at N > 1 the 10M-row base follows as `paths` entries)")
+    ap.add_argument("--big-rows", type=int, default=10_000_000,
+                    help="N > 1, --rows not given: rows of the second, larger base (0 = skip it)")
+    ap.add_argument("--headline-rows", type=int, default=1_000_000,
+                    help="rows of the base `value` is measured on when --rows is not given (the metric's 1M; smaller in tests)")
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--queries", type=int, default=10_000)
     ap.add_argument("--k", type=int, default=10)
@@ -323,14 +330,38 @@ def oracle_sharded_truth(be, orc, args, metric, queries_host, n_shards_rows):
 
 
 def run(args, be):
-    """The benchmark's control flow on backend `be`; returns the JSON line on rank 0 (None elsewhere)."""
+    """The benchmark's control flow on backend `be`; returns the JSON line on rank 0 (None elsewhere).
+
+    One GPU, or --rows given: one workload.  N > 1 by default: the N = 1 workload (1M rows) split by rows gives `value`,
+    then the metric's 10M-row base, split the same way, is measured by the same code and folded into `paths`."""
+    shard = args.shard or ("rows" if be.world > 1 else "queries")
+    if not (shard == "rows" and be.world > 1 and args.rows is None and args.big_rows > 0):
+        return run_workload(args, be, args.rows if args.rows is not None else args.headline_rows, "only")
+    head = run_workload(args, be, args.headline_rows, "headline")
+    big = run_workload(args, be, args.big_rows, "big", outer=head)
+    if head is not None and big is not None:
+        cfg = big["config"]
+        entry = {"path": "flat10m_sharded", "workload": cfg["workload"], "queries": cfg["queries"], "n_gpus": big["n_gpus"],
+                 "ms_per_batch": big["ms_per_step"], "qps": big["value"], "first_pass": cfg["first_pass"],
+                 "rows_total": cfg["rows_total"], "rows_per_gpu": cfg["rows_per_gpu"], "sharding": cfg["sharding"],
+                 "exchange": cfg["exchange"], "roofline": big["roofline"], "parity": big["parity"],
+                 "single_gpu_same_workload": cfg.get("single_gpu_same_workload"),
+                 "refined_per_batch": big["refined_queries_per_step"], "fallback_per_batch": big["fallback_queries_per_step"],
+                 "index_build_s": big["index_build_s"]}
+        head["paths"] = [entry] + list(big.get("paths") or [])
+    return head
+
+
+def run_workload(args, be, rows_total, role, outer=None):
+    """One flat workload of `rows_total` rows.  role "only": everything the line carries; "headline": the N > 1 headline (no
+    IVF leg); "big": the larger base behind it (one first-pass precision, no CPU legs; `outer` is the headline's line, which
+    the watchdog of the collective IVF leg prints should a rank stall)."""
     from needle_amd.distance import DistanceFunction
     from needle_amd.sharded import shard_bounds
 
     rank, world = be.rank, be.world
     shard = args.shard or ("rows" if world > 1 else "queries")
     by_rows = shard == "rows" and world > 1
-    rows_total = args.rows if args.rows is not None else (10_000_000 if by_rows else 1_000_000)
     spans = [shard_bounds(rows_total, world, r, GEN_CHUNK) for r in range(world)] if by_rows else [(0, rows_total)] * world
     lo, hi = spans[rank]
     metric = DistanceFunction.from_str(args.metric)
@@ -404,7 +435,7 @@ def run(args, be):
     roofline = roofline_of(args.precision, m)
 
     secondary = None
-    if args.secondary_steps > 0:
+    if args.secondary_steps > 0 and role != "big":
         other = "fp32" if args.precision == "bf16" else "bf16"
         el2, m2, _ = timed(other, args.secondary_steps, 1)
         secondary = {"first_pass": other, "value": round(total_queries * args.secondary_steps / el2, 1),
@@ -450,7 +481,7 @@ def run(args, be):
         host_pointer = be.host_pointer_qps(index, be.host(queries), args.k, args.precision)
     index.close()
     want_paths = [] if args.paths in ("", "none") else args.paths.split(",")
-    sharded_ivf = by_rows and world > 1 and "ivf" in want_paths and hasattr(be, "ivf_sharded")
+    sharded_ivf = by_rows and world > 1 and "ivf" in want_paths and hasattr(be, "ivf_sharded") and role != "headline"
     if not sharded_ivf:
         del base
     if rank == 0 and world == 1 and want_paths:
@@ -472,8 +503,8 @@ def run(args, be):
                        "rows_total": rows_total, "rows_per_gpu": hi - lo, "dim": args.dim, "queries": args.queries,
                        "k": args.k, "first_pass": args.precision, "queries_total": total_queries,
                        "sharding": sharding, "exchange": be.exchange_label() if by_rows else None,
-                       "scaling_reference": ("the same 10M-row base on ONE GPU is the `flat10m` entry of the N = 1 line's `paths` "
-                                             "(the N = 1 headline itself is the 1M-row configuration of the metric)")
+                       "scaling_reference": ("`value` at every N is this same workload (the N = 1 run of this script); rank 0 also "
+                                             "times it alone on its GPU in this run: single_gpu_same_workload")
                        if by_rows and world > 1 else None,
                        "recall_at_10": 1.0 if parity is not None and parity["ids_equal"] else None},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
@@ -493,11 +524,12 @@ def run(args, be):
         def bail():
             if done.is_set():
                 return
-            if line is not None:
-                line["paths"] = [{"path": "ivf_sharded", "error": f"not finished within {args.ivf_leg_seconds:.0f} s"}]
-                print(json.dumps(line), flush=True)
+            shown = outer if outer is not None else line  # the headline's line when this is the larger base behind it
+            if shown is not None:
+                shown["paths"] = [{"path": "ivf_sharded", "error": f"not finished within {args.ivf_leg_seconds:.0f} s"}]
+                print(json.dumps(shown), flush=True)
             # a stalled collective leg is a failed run: the flat line is out, the exit status says so (3 = parity, 4 = stall)
-            os._exit(4 if line is None or parity_ok(line) else 3)
+            os._exit(4 if shown is None or parity_ok(shown) else 3)
 
         dog = threading.Timer(args.ivf_leg_seconds, bail)
         dog.daemon = True
@@ -512,8 +544,8 @@ def run(args, be):
         if line is not None:
             line["paths"] = [leg]
     if by_rows and world > 1 and not args.no_scaling_reference:
-        # The strong-scaling reference of THIS workload: rank 0 searches the whole base on its own GPU while the others
-        # wait (the N = 1 run of the contract measures the metric's 1M-row configuration, a different workload).
+        # The strong-scaling reference of THIS workload inside this run: rank 0 searches the whole base on its own GPU
+        # while the others wait.
         if rank == 0:
             try:
                 full = be.rows(rows_total, args.dim, 42)

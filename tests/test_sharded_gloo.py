@@ -226,6 +226,29 @@ def test_bench_control_flow_row_shards_by_default(tmp_path, oracle):
     assert line["config"]["recall_at_10"] == 1.0 and line["unit"] == "queries/s" and line["value"] > 0
 
 
+def test_bench_two_workloads_at_n_gt_1(tmp_path, oracle):
+    """`bench.py --gpus 2` without --rows: `value` comes from the N = 1 workload split by rows, the larger base is measured
+    by the same code and arrives as the `flat10m_sharded` entry of `paths`, with its own parity sample."""
+    world = 2
+    argv = ["--gpus", "2", "--headline-rows", "10000", "--big-rows", "25000", "--dim", "24", "--queries", "12", "--k", "5",
+            "--steps", "1", "--warmup", "0", "--secondary-steps", "0", "--parity-queries", "12"]
+    mp.spawn(_bench_worker, args=(world, _free_port(), argv, str(tmp_path)), nprocs=world, join=True)
+    line = json.load(open(tmp_path / "bench0.json"))["line"]
+    assert json.load(open(tmp_path / "bench1.json"))["line"] is None
+    assert line["config"]["rows_total"] == 10000 and line["scaling"] == "strong" and line["n_gpus"] == 2
+    assert line["parity"]["ids_equal"] and line["parity"]["dists_bit_equal"]
+    assert line["config"]["single_gpu_same_workload"]["value"] > 0
+    (big,) = line["paths"]
+    assert big["path"] == "flat10m_sharded" and big["rows_total"] == 25000 and big["rows_per_gpu"] == 15000
+    assert big["parity"] == {"queries_checked": 12, "rank": 0, "ids_equal": True, "dists_bit_equal": True}
+    assert big["single_gpu_same_workload"]["value"] > 0 and big["qps"] > 0
+    import bench
+
+    assert bench.parity_ok(line)
+    big["parity"]["ids_equal"] = False
+    assert not bench.parity_ok(line)
+
+
 def test_bench_defaults():
     sys.path.insert(0, ROOT)
     import bench
@@ -234,8 +257,10 @@ def test_bench_defaults():
     assert a.gpus == 1 and a.rows is None and a.shard is None and a.precision == "bf16"
     import inspect
 
+    # `value` is measured on the metric's 1M-row base at every N; at N > 1 its 10M-row base follows as `paths` entries
+    assert a.headline_rows == 1_000_000 and a.big_rows == 10_000_000
     src = inspect.getsource(bench.run)
-    assert "10_000_000 if by_rows else 1_000_000" in src  # N > 1: the 10M base of the metric, split by rows
+    assert 'run_workload(args, be, args.headline_rows, "headline")' in src and 'run_workload(args, be, args.big_rows, "big"' in src
     assert not bench.parity_ok({"parity": {"ids_equal": False, "dists_bit_equal": True}})
     assert bench.parity_ok({"parity": None, "paths": [{"parity": {"ids_equal": True, "queries_checked": 0}}]})
 
