@@ -6,7 +6,7 @@ the reference's operator interface.  There is no CPU fallback.
 """
 from . import _lib
 from ._lib import DimensionMismatch, InvalidVector, NeedleHipError
-from .accelerator import GpuAccelerator, GpuResidentIndex
+from .accelerator import FallbackSearchResult, GpuAccelerator, GpuResidentIndex, TransparentFallbackManager
 from .collection import Collection, SearchResult
 from .distance import DistanceFunction, DistanceType, normalize, normalized
 from .index import Context, FlatIndex, pack_bitmask

@@ -162,6 +162,93 @@ class GpuAccelerator:
         return self.ctx.metrics()
 
 
+class FallbackSearchResult:
+    """`FallbackSearchResult`, src/experimental/gpu/mod.rs:1398-1403."""
+
+    __slots__ = ("results", "backend_used", "elapsed")
+
+    def __init__(self, results: List[Hit], backend_used: str, elapsed: float):
+        self.results, self.backend_used, self.elapsed = results, backend_used, elapsed
+
+
+class TransparentFallbackManager:
+    """The reference's failure bookkeeping around one-query searches (`TransparentFallbackManager`,
+    src/experimental/gpu/mod.rs:1407-1560): every device error counts, from the fourth on the device path is switched off
+    for `backoff_secs` (5 s, doubling up to 300 s), and `gpu_reliability` is successes over attempts.
+
+    The reference answers a failed or switched-off call from its own scalar loop.  This package holds no host
+    implementation of any search: the caller's existing path is passed in as `cpu_search(query, vectors, k, distance)`
+    (Needle's own `cpu_search`, mod.rs:1496-1541), and without one the device error is raised to the caller."""
+
+    GPU, CPU = "Gpu", "CpuSimd"  # ExecutionBackend variants the reference reports
+
+    def __init__(self, accelerator: GpuAccelerator, cpu_search: Callable | None = None, clock: Callable[[], float] | None = None):
+        import time
+
+        self.accelerator = accelerator
+        self.cpu_search = cpu_search
+        self._clock = clock or time.monotonic
+        self.reset()
+
+    def reset(self) -> None:  # mod.rs:1554-1559
+        self.gpu_failures = 0
+        self.gpu_successes = 0
+        self.gpu_disabled_until: float | None = None
+        self.backoff_secs = 5
+
+    def gpu_reliability(self) -> float:  # mod.rs:1544-1551
+        total = self.gpu_successes + self.gpu_failures
+        return 1.0 if total == 0 else self.gpu_successes / total
+
+    def _try_gpu_search(self, query, vectors, k: int, distance: DistanceType) -> List[Hit]:  # mod.rs:1476-1494
+        fn = {DistanceType.Cosine: self.accelerator.batch_cosine_distance,
+              DistanceType.Euclidean: self.accelerator.batch_euclidean_distance,
+              DistanceType.DotProduct: self.accelerator.batch_dot_product}[DistanceType(distance)]
+        d = fn(query, vectors)
+        # sort_by(partial_cmp ... unwrap_or(Equal)) is a stable sort: equal distances keep their index order
+        order = sorted(range(len(d)), key=lambda i: d[i]) if not np.isnan(d).any() else _partial_cmp_sort(d)
+        return [(int(i), float(d[i])) for i in order[:k]]
+
+    def search(self, query, vectors, k: int, distance: DistanceType) -> FallbackSearchResult:  # mod.rs:1427-1474
+        start = self._clock()
+        gpu_available = True
+        if self.gpu_disabled_until is not None:
+            if self._clock() < self.gpu_disabled_until:
+                gpu_available = False
+            else:
+                self.gpu_disabled_until = None
+        error = None
+        if gpu_available:
+            try:
+                results = self._try_gpu_search(query, vectors, k, distance)
+                self.gpu_successes += 1
+                return FallbackSearchResult(results, self.GPU, self._clock() - start)
+            except _lib.NeedleHipError as e:
+                error = e
+                self.gpu_failures += 1
+                if self.gpu_failures > 3:
+                    self.gpu_disabled_until = self._clock() + self.backoff_secs
+                    self.backoff_secs = min(self.backoff_secs * 2, 300)
+        if self.cpu_search is None:
+            raise error if error is not None else _lib.NeedleHipError(
+                _lib.ERR_NO_DEVICE, "device path switched off after repeated failures and no cpu_search was given")
+        results = self.cpu_search(query, vectors, k, distance)
+        return FallbackSearchResult(list(results), self.CPU, self._clock() - start)
+
+
+def _partial_cmp_sort(d) -> List[int]:
+    """Rust's `sort_by(|a, b| a.partial_cmp(b).unwrap_or(Equal))` with NaNs present: a stable merge sort under a
+    comparison that calls NaN equal to everything (insertion by that comparison reproduces small inputs; the order of a
+    non-transitive comparison is otherwise unspecified in the reference too)."""
+    import functools
+
+    def cmp(i, j):
+        a, b = d[i], d[j]
+        return -1 if a < b else (1 if a > b else 0)
+
+    return sorted(range(len(d)), key=functools.cmp_to_key(cmp))
+
+
 class GpuResidentIndex:
     """`GpuResidentIndex` (src/experimental/gpu/mod.rs:1102-1213): vectors stay on the device between searches.
     `add` / `add_batch` queue rows on the host; the next search appends the queued rows to the resident index
