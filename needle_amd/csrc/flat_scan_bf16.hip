@@ -57,8 +57,13 @@ constexpr int BF_STAGE_BYTES = BF_ROWS * BF_BK * 2;       // 16 KB
 #ifndef BF_RING_AHEAD
 #define BF_RING_AHEAD 3
 #endif
+#ifndef BF_BARRIER_EVERY
+#define BF_BARRIER_EVERY 1  // stages per workgroup barrier (1 or 2; 2 needs BF_RING_SLOTS == BF_RING_AHEAD + 2)
+#endif
 constexpr int BF_NBUF = BF_RING_SLOTS;                    // ring slots
 constexpr int BF_PD = BF_RING_AHEAD;                      // stages in flight ahead of the one being multiplied (< BF_NBUF)
+constexpr int BF_BE = BF_BARRIER_EVERY;
+static_assert(BF_BE == 1 ? BF_NBUF >= BF_PD + 1 : BF_NBUF == BF_PD + BF_BE, "ring slots against stages ahead");
 
 // byte offset of 16-byte chunk c (0..15) of row r (0..63) inside a stage: rows are 256 B = one sweep of
 // the LDS banks, so the 16 rows one ds_read_b128 phase touches are spread over the 16 chunk positions
@@ -70,10 +75,11 @@ constexpr int bf_stage_loads(int u) { return PIECES + ((CINIT && (u % STAGES) ==
 // loads issued behind stage u that may still be in flight when stage u is awaited
 // loads that may stay in flight while stage u + 1 is awaited at the fill point of stage u: those of stages
 // u + 2 .. u + BF_PD - 1 (stage u + BF_PD is issued right behind that wait)
+// (a barrier every second stage awaits stages u + 1 AND u + 2: those of stages u + 3 .. u + BF_PD - 1 may stay in flight)
 template <int STAGES, bool CINIT, int PIECES = 4>
 constexpr int bf_steady_inflight(int u) {
     int n = 0;
-    for (int j = 2; j < BF_PD; ++j) n += bf_stage_loads<STAGES, CINIT, PIECES>(u + j);
+    for (int j = 1 + BF_BE; j < BF_PD; ++j) n += bf_stage_loads<STAGES, CINIT, PIECES>(u + j);
     return n;
 }
 template <int STAGES, bool CINIT, int PIECES = 4>
@@ -292,8 +298,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 || (BF_FLAT_WG4X2 && KS32 <
             for (uint32_t jj = t0; jj < t1; ++jj) {
                 static_for<UT>([&](auto u_c) {
                     constexpr int u = decltype(u_c)::value;
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_steady_inflight<STAGES, CINIT, PIECES>(u)) : "memory");
-                    __builtin_amdgcn_s_barrier();
+                    if (u % BF_BE == 0) {
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_steady_inflight<STAGES, CINIT, PIECES>(u)) : "memory");
+                        __builtin_amdgcn_s_barrier();
+                    }
 #pragma unroll
                     for (int i = 0; i < PIECES; ++i)
                         issue_piece(min(jj + (uint32_t)((u + BF_PD) / UT), t1 - 1), (u + BF_PD) % UT, (slot + BF_PD) % BF_NBUF, i);
@@ -337,7 +345,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 || (BF_FLAT_WG4X2 && KS32 <
                         // barrier then holds the second wave of every SIMD half a stage behind the first, so that one's
                         // selection phase runs beside the other's MFMAs instead of both stalling together.
                         if ((kk < 2) == lag) {
-                            if (kk == 0 || kk == 2) {
+                            // (with a barrier every second stage the waves of a workgroup may drift a stage apart between
+                            // two of them: a wave held up by a list push no longer holds up the other seven at once)
+                            if ((kk == 0 || kk == 2) && u % BF_BE == 0) {
                                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_steady_inflight<STAGES, CINIT, PIECES>(u)) : "memory");
                                 __builtin_amdgcn_s_barrier();
                             }
