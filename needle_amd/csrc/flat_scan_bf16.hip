@@ -37,6 +37,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
@@ -366,7 +367,13 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 || (BF_FLAT_WG4X2 && KS32 <
                         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                             for (int t = 0; t < NTQ; ++t)
+#ifdef BF_DEV_I8SIM  // development, timing only (results are garbage): the same loop issuing v_mfma_i32_16x16x64_i8 on the same registers
+                                acc[mt][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(
+                                    __builtin_bit_cast(i32x4, a[kk % 2][mt]), __builtin_bit_cast(i32x4, bq[t][g]),
+                                    __builtin_bit_cast(i32x4, acc[mt][t]), 0, 0, 0));
+#else
                                 acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk % 2][mt], bq[t][g], acc[mt][t], 0, 0, 0);
+#endif
                     });
                     slot = (slot + 1) % BF_NBUF;
                 });
