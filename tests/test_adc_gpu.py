@@ -31,7 +31,9 @@ def _cmp(got, want):
         assert np.all(ids[i, c:] == U64MAX)
 
 
-@pytest.mark.parametrize("shape", [(5000, 32, 4, 10), (20000, 96, 12, 10), (3000, 30, 5, 7), (70000, 384, 48, 10)])
+@pytest.mark.parametrize("shape", [(5000, 32, 4, 10), (20000, 96, 12, 10), (3000, 30, 5, 7), (70000, 384, 48, 10),
+                                   # 20 and 33 subspaces: a last table slice of 4 and of 1; fewer rows than a lane group; k = 256
+                                   (4001, 40, 20, 10), (2500, 66, 33, 3), (13, 32, 16, 5), (30000, 68, 17, 256)])
 def test_pq_table_scan(ctx, oracle, shape):
     from needle_amd.quantization import PqIndex, ProductQuantizer
 
