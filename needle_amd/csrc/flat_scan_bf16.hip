@@ -52,19 +52,25 @@ typedef const __attribute__((address_space(1))) void glb_void;
 constexpr int BF_ROWS = 64;                               // rows per stage: half a 128-row tile
 constexpr int BF_BK = 128;                                // dims per stage
 constexpr int BF_STAGE_BYTES = BF_ROWS * BF_BK * 2;       // 16 KB
-#ifndef BF_RING_SLOTS
-#define BF_RING_SLOTS 4
+// The ring of staged half-tile slices.  A workgroup meets at a barrier every `be` stages; between two barriers its waves
+// may drift up to `be - 1` stages apart, so a wave held up by a list push does not hold up the other seven at once
+// (two stages per barrier against one: 1.5 % on 1M and 10M rows, 3-5 % on shards of 125K-250K rows, SQ8 1.4 %; three
+// stages no better).  Fills run `pd` stages ahead of the stage being multiplied and the ring has pd + be slots: the
+// barrier of stage u proves stages u + 1 .. u + be landed and every wave out of stages <= u - 1, whose slots take the
+// fills issued during stages u .. u + be - 1.  Inverted-list scans keep one stage per barrier: their two workgroups per
+// CU leave room for four slots each.
+#ifndef BF_BARRIER_EVERY
+#define BF_BARRIER_EVERY 2
 #endif
 #ifndef BF_RING_AHEAD
-#define BF_RING_AHEAD 3
+#define BF_RING_AHEAD 4
 #endif
-#ifndef BF_BARRIER_EVERY
-#define BF_BARRIER_EVERY 1  // stages per workgroup barrier (1 or 2; 2 needs BF_RING_SLOTS == BF_RING_AHEAD + 2)
+#if defined(BF_FLAT_WG4X2) && BF_FLAT_WG4X2 && BF_BARRIER_EVERY != 1
+#error "two four-wave workgroups per CU leave room for four ring slots each: build with -DBF_BARRIER_EVERY=1 -DBF_RING_AHEAD=3"
 #endif
-constexpr int BF_NBUF = BF_RING_SLOTS;                    // ring slots
-constexpr int BF_PD = BF_RING_AHEAD;                      // stages in flight ahead of the one being multiplied (< BF_NBUF)
-constexpr int BF_BE = BF_BARRIER_EVERY;
-static_assert(BF_BE == 1 ? BF_NBUF >= BF_PD + 1 : BF_NBUF == BF_PD + BF_BE, "ring slots against stages ahead");
+template <int MODE> constexpr int bf_be() { return MODE == MODE_IVF ? 1 : BF_BARRIER_EVERY; }
+template <int MODE> constexpr int bf_pd() { return MODE == MODE_IVF ? 3 : BF_RING_AHEAD; }
+template <int MODE> constexpr int bf_nbuf() { return bf_pd<MODE>() + bf_be<MODE>(); }
 
 // byte offset of 16-byte chunk c (0..15) of row r (0..63) inside a stage: rows are 256 B = one sweep of
 // the LDS banks, so the 16 rows one ds_read_b128 phase touches are spread over the 16 chunk positions
@@ -75,18 +81,18 @@ template <int STAGES, bool CINIT, int PIECES = 4>
 constexpr int bf_stage_loads(int u) { return PIECES + ((CINIT && (u % STAGES) == 0) ? 1 : 0); }
 // loads issued behind stage u that may still be in flight when stage u is awaited
 // loads that may stay in flight while stage u + 1 is awaited at the fill point of stage u: those of stages
-// u + 2 .. u + BF_PD - 1 (stage u + BF_PD is issued right behind that wait)
-// (a barrier every second stage awaits stages u + 1 AND u + 2: those of stages u + 3 .. u + BF_PD - 1 may stay in flight)
-template <int STAGES, bool CINIT, int PIECES = 4>
+// u + 2 .. u + PD - 1 (stage u + PD is issued right behind that wait)
+// (a barrier every second stage awaits stages u + 1 AND u + 2: those of stages u + 3 .. u + PD - 1 may stay in flight)
+template <int STAGES, bool CINIT, int PIECES, int PD, int BE>
 constexpr int bf_steady_inflight(int u) {
     int n = 0;
-    for (int j = 1 + BF_BE; j < BF_PD; ++j) n += bf_stage_loads<STAGES, CINIT, PIECES>(u + j);
+    for (int j = 1 + BE; j < PD; ++j) n += bf_stage_loads<STAGES, CINIT, PIECES>(u + j);
     return n;
 }
-template <int STAGES, bool CINIT, int PIECES = 4>
+template <int STAGES, bool CINIT, int PIECES, int PD>
 constexpr int bf_inflight_behind(int u) {
     int n = 0;
-    for (int j = 1; j < BF_PD; ++j) n += bf_stage_loads<STAGES, CINIT, PIECES>(u + j);
+    for (int j = 1; j < PD; ++j) n += bf_stage_loads<STAGES, CINIT, PIECES>(u + j);
     return n;
 }
 
@@ -148,6 +154,7 @@ __device__ inline void push_lane16(const f32x4 (&acc)[4], uint32_t row_base, uin
 #endif
 template <int MODE, int NTQ, int KS32, bool CINIT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 || (BF_FLAT_WG4X2 && KS32 <= 12)) ? 2 : 1) void flat_scan_bf16x_kernel(ScanParams p) {
+    constexpr int BF_BE = bf_be<MODE>(), BF_PD = bf_pd<MODE>(), BF_NBUF = bf_nbuf<MODE>();  // stages per barrier, stages ahead, ring slots
     constexpr int CSLOT = 256 * WAVES;   // per slot: the half tile's accumulator seeds, once per wave
     constexpr int PIECES = 16 / WAVES;   // fill pieces (4 rows x 256 B) a wave issues per stage
     __shared__ __attribute__((aligned(1024))) unsigned char smem[BF_NBUF * (BF_STAGE_BYTES + CSLOT)];
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 || (BF_FLAT_WG4X2 && KS32 <
 
 #pragma unroll
         for (int j = 0; j < BF_PD; ++j) issue_stage(min(t0 + (uint32_t)(j / UT), t1 - 1), j % UT, (uint32_t)j);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_inflight_behind<STAGES, CINIT, PIECES>(0)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_inflight_behind<STAGES, CINIT, PIECES, BF_PD>(0)) : "memory");
         __builtin_amdgcn_s_barrier();
         uint32_t slot = 0;
         if (BF_SKIPS_DEAD(MODE) && !wave_live) {
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 || (BF_FLAT_WG4X2 && KS32 <
                 static_for<UT>([&](auto u_c) {
                     constexpr int u = decltype(u_c)::value;
                     if (u % BF_BE == 0) {
-                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_steady_inflight<STAGES, CINIT, PIECES>(u)) : "memory");
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_steady_inflight<STAGES, CINIT, PIECES, BF_PD, BF_BE>(u)) : "memory");
                         __builtin_amdgcn_s_barrier();
                     }
 #pragma unroll
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 || (BF_FLAT_WG4X2 && KS32 <
                             // (with a barrier every second stage the waves of a workgroup may drift a stage apart between
                             // two of them: a wave held up by a list push no longer holds up the other seven at once)
                             if ((kk == 0 || kk == 2) && u % BF_BE == 0) {
-                                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_steady_inflight<STAGES, CINIT, PIECES>(u)) : "memory");
+                                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(bf_steady_inflight<STAGES, CINIT, PIECES, BF_PD, BF_BE>(u)) : "memory");
                                 __builtin_amdgcn_s_barrier();
                             }
 #pragma unroll
