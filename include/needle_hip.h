@@ -178,11 +178,16 @@ needle_hip_status needle_hip_reset_metrics(needle_hip_ctx* ctx);
  * in the reference (its GpuConfig, src/experimental/gpu/common.rs:143-175, holds
  * the analogous knobs).  The library reads no environment variable: tests use
  * this call to force a code path, the A/B tools to sweep a parameter.  Overrides
- * move plans and cost, never results.  Keys: "splits", "pre_tiles", "kseed",
+ * move plans and cost, never results -- with one exception, the timing
+ * experiments among the "debug" bits.  Keys: "splits", "pre_tiles", "kseed",
  * "band", "stage0".."stage3" (percent of a slice per staged launch),
  * "no_dense", "no_set_only", "merge_keys", "merge_lists", "rs_cap", "rs_dc",
- * "ivf_no_seed", "ivf_seed_rows", "ivf_split", "binary_two_scans", "debug" (bit 3: print what
- * the first pass listed), "trace" and "poison" (process-wide), "reset" (back to
+ * "ivf_no_seed", "ivf_seed_rows", "ivf_split", "binary_two_scans", "no_compact",
+ * "compact_pct", "compact_min_rows", "debug" (bit 1: no threshold seeding, bit 2:
+ * one launch per slice, bit 3: print what the first pass listed, bit 4: no
+ * candidate pruning; bits 0, 8 and 9 switch off the selection, the table refill
+ * and the table lookups of a scan to time what is left: a search run under them
+ * returns WRONG results), "trace" and "poison" (process-wide), "reset" (back to
  * the built-in choices).  Unknown keys fail with
  * NEEDLE_HIP_ERR_INVALID_ARGUMENT. */
 needle_hip_status needle_hip_set_tuning(needle_hip_ctx* ctx, const char* key, double value);

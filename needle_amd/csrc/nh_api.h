@@ -69,8 +69,9 @@ struct DevBuf {
 // Planning overrides of a context (needle_hip_set_tuning): what tests use to force a code path and what the A/B tools
 // sweep.  They move plans and cost, never results.  0 / negative = the built-in choice.
 struct Tuning {
-    uint32_t debug = 0;          // 1 selection off (timing only), 2 no threshold seeding, 4 one launch per slice, 8 print what the
-                                 // first pass listed, 16 no candidate pruning, 64 print the in-kernel clock (stamp build)
+    uint32_t debug = 0;          // 1 selection off (timing only: wrong results), 2 no threshold seeding, 4 one launch per slice,
+                                 // 8 print what the first pass listed, 16 no candidate pruning, 64 print the in-kernel clock
+                                 // (stamp build); PQ table scan, timing only: 256 tables filled once, 512 no lookups
     uint32_t splits = 0;         // slices of the base per query block
     int32_t pre_tiles = -1;      // tiles per slice the threshold pre-pass samples
     uint32_t kseed = 0;          // rank of the seeded threshold among the sampled group maxima
