@@ -118,6 +118,7 @@ def test_pq_table_scan_seeded_thresholds(ctx, oracle):
             _cmp(ix.search(queries, k), opq.batch_search(queries, codes, k, valid=valid))
             _cmp(ix.search(queries, 1), opq.batch_search(queries, codes, 1, valid=valid))
             _cmp(ix.search(queries, 100), opq.batch_search(queries, codes, 100, valid=valid))
+            _cmp(ix.search(queries[:6], 256), opq.batch_search(queries[:6], codes, 256, valid=valid))  # lists of 576 entries
             _cmp(ix.search(queries, k, filter_mask=few), opq.batch_search(queries, codes, k, valid=valid & few))
             _cmp(ix.search(queries, k, filter_mask=sparse), opq.batch_search(queries, codes, k, valid=valid & sparse))
     finally:
