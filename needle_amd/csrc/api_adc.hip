@@ -94,9 +94,10 @@ needle_hip_status nh::pq_search_batch_device(needle_hip_index* ix, const float* 
         const uint32_t pre_S = 8, pre_rows = (forced ? 1 : 2) * pq_scan_block_rows();
         const bool seed = n >= (forced ? 2 : 16) * pre_S * pre_rows && !(c->tune.debug & 2u) && xcd_slots % pre_S == 0;
         const uint32_t lists_per_q = PQ_WAVES * S, pre_lists_per_q = PQ_WAVES * pre_S, max_lists = std::max(lists_per_q, seed ? pre_lists_per_q : 0u);
+        const uint32_t pre_cap = 2 * k + 64;  // the sample's many short-lived lists stay small (they may compact as they go)
 
         HIP_TRY(ix->w_pqtab.ensure(pq_table_bytes(qc, m)));
-        HIP_TRY(ix->w_lists.ensure((size_t)qc * max_lists * cap * sizeof(uint2)));
+        HIP_TRY(ix->w_lists.ensure(std::max((size_t)qc * lists_per_q * cap, seed ? (size_t)qc * pre_lists_per_q * pre_cap : (size_t)0) * sizeof(uint2)));
         HIP_TRY(ix->w_lcnt.ensure((size_t)qc * max_lists * sizeof(uint32_t)));
         HIP_TRY(ix->w_cand.ensure((size_t)qc * k * sizeof(uint32_t)));
         HIP_TRY(ix->w_scores.ensure((size_t)qc * k * sizeof(float)));
@@ -130,9 +131,11 @@ needle_hip_status nh::pq_search_batch_device(needle_hip_index* ix, const float* 
         if (seed) {
             HIP_TRY(hipMemsetAsync(ix->w_lcnt.p, 0, (size_t)qc * pre_lists_per_q * sizeof(uint32_t), c->stream));
             sp.n_splits = pre_S; sp.rows_per_split = pre_rows; sp.split_stride = n / pre_S / PQ_SG * PQ_SG; sp.tau_seed = nullptr;
+            sp.cap = pp.cap = pre_cap;
             HIP_TRY(launch_pq_scan(sp, c->stream));
             pp.n_splits = pre_lists_per_q;
             HIP_TRY(launch_merge_select(pp, c->stream));  // tau_star: the k-th best score of the sample (-inf: fewer than k live rows)
+            sp.cap = pp.cap = cap;
         }
         HIP_TRY(hipMemsetAsync(ix->w_lcnt.p, 0, (size_t)qc * lists_per_q * sizeof(uint32_t), c->stream));
         sp.n_splits = S; sp.rows_per_split = rows_per_split; sp.split_stride = rows_per_split;
